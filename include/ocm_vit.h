@@ -1,0 +1,224 @@
+/*
+ * ocm_vit.h — C ABI of the MI355X (gfx950) ViT attention-map engine.
+ *
+ * The reference (linum-uqam/ViT-OCM-WMSegmentation) has NO native/FFI layer: its
+ * boundary is the Python nn.Module surface of
+ *   Self-supervised_segmentation/dino/vision_transformer.py
+ * (SURVEY.md §8-b).  This header is therefore the ABI that the build's Python
+ * mirror of that module binds through ctypes; every entry point names the
+ * reference lines whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types.
+ *   - every pointer marked "dev" is a device (HBM) pointer owned by the caller
+ *     unless stated otherwise; nothing here allocates caller-visible memory.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream). No entry
+ *     point synchronises the device; all work is enqueued on `stream`.
+ *   - return value: 0 = OCM_OK, otherwise an OCM_E* code; ocm_last_error() gives
+ *     the message of the last failure on the calling thread.
+ *   - thread-compatible: one ocm_vit_t per model, no globals besides the
+ *     thread-local error string.
+ */
+#ifndef OCM_VIT_H
+#define OCM_VIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCM_ABI_VERSION 1
+
+enum {
+    OCM_OK = 0,
+    OCM_EINVAL = 1,     /* bad argument / unsupported shape (Python: ValueError)      */
+    OCM_ESTATE = 2,     /* parameter missing, handle not ready (Python: RuntimeError) */
+    OCM_EHIP = 3,       /* HIP runtime / launch failure (Python: RuntimeError)        */
+    OCM_ENOMEM = 4,     /* workspace too small / allocation failure                    */
+    OCM_ENAME = 5       /* unknown parameter name (Python: KeyError)                   */
+};
+
+/* Arithmetic of the contraction kernels. The residual stream, LayerNorm
+ * statistics, softmax and all accumulators are fp32 in every mode. */
+enum {
+    OCM_PREC_BF16 = 0,   /* bf16 MFMA operands, fp32 accumulate                        */
+    OCM_PREC_BF16X3 = 1  /* split-bf16 (hi+lo) operands, 3 MFMAs per product (~fp32)   */
+};
+
+/* Hyper-parameters: VisionTransformer.__init__ (vision_transformer.py:137-165) and
+ * the vit_tiny/small/base factories (:259-279). head_dim = embed_dim/num_heads
+ * must be 64 (true for T/S/B). */
+typedef struct ocm_vit_config {
+    int32_t patch_size;   /* p: 8 or 16 (any multiple of 8 up to 32)                   */
+    int32_t in_chans;     /* 3 (reference) or 1 (grayscale-folded patch embedding)     */
+    int32_t embed_dim;    /* D, multiple of 64                                         */
+    int32_t depth;        /* L                                                         */
+    int32_t num_heads;    /* H = D/64                                                  */
+    int32_t mlp_hidden;   /* int(D*mlp_ratio), multiple of 64                          */
+    float ln_eps;         /* 1e-6 for the DINO factories (:262,268,277)                */
+    float qk_scale;       /* head_dim^-0.5 unless qk_scale was given (:71)             */
+    int32_t precision;    /* OCM_PREC_*                                                */
+    int32_t reserved;
+} ocm_vit_config;
+
+typedef struct ocm_vit ocm_vit_t; /* opaque engine handle */
+
+/* ---- library --------------------------------------------------------------- */
+int ocm_abi_version(void);
+const char *ocm_last_error(void);
+
+/* ---- handle life cycle ----------------------------------------------------- */
+int ocm_vit_create(const ocm_vit_config *cfg, ocm_vit_t **out);
+void ocm_vit_destroy(ocm_vit_t *h);
+
+/* Upload one parameter. `name` is the reference state_dict key:
+ *   cls_token, patch_embed.proj.{weight,bias}, blocks.{i}.norm1.{weight,bias},
+ *   blocks.{i}.attn.qkv.{weight,bias}, blocks.{i}.attn.proj.{weight,bias},
+ *   blocks.{i}.norm2.{weight,bias}, blocks.{i}.mlp.fc1.{weight,bias},
+ *   blocks.{i}.mlp.fc2.{weight,bias}, norm.{weight,bias}
+ * (`pos_embed` is passed per forward, see ocm_vit_io.pos_embed).
+ * `dev_src` is a contiguous fp32 device buffer of `count` elements in the
+ * reference's layout; the engine keeps its own packed (bf16 for matrices, fp32
+ * for vectors) copy, so the source may be freed after the stream has run. */
+int ocm_vit_set_param(ocm_vit_t *h, const char *name, const float *dev_src, size_t count,
+                      void *stream);
+/* 0 when every parameter has been set, else OCM_ESTATE with the first missing
+ * name in ocm_last_error(). */
+int ocm_vit_params_ready(const ocm_vit_t *h);
+
+/* ---- forward --------------------------------------------------------------- */
+enum {
+    OCM_OUT_FEAT = 1 << 0,      /* norm(x) of the last n blocks       (get_intermediate_feat :234)  */
+    OCM_OUT_ATTN = 1 << 1,      /* softmax probabilities (B,H,N,N)    (Attention.forward :83-85)    */
+    OCM_OUT_QKV = 1 << 2,       /* (3,B,H,N,64) fp32                  (Attention.forward :80)       */
+    OCM_OUT_TOKENS = 1 << 3,    /* raw residual stream after the last block (no final norm)         */
+    OCM_OUT_ROWS = 1 << 4,      /* selected query rows of the last block's attention, CLS column
+                                   dropped: (B,H,n_rows,N-1)          (utils.py:229-233)            */
+    OCM_LAST_ATTN_ONLY = 1 << 5 /* get_last_selfattention (:239-246): the last block stops after
+                                   its attention probabilities; FEAT/TOKENS/QKV must not be set.    */
+};
+
+/* One batch of tiles through prepare_tokens + blocks [+ final norm].
+ * Tiles are p-aligned windows of fp32 planar images resident in HBM:
+ *   pixel(b, c, y, x) = image[ b*img_stride_b + c*img_stride_c
+ *                              + (y0_b + y)*img_stride_y + (x0_b + x) ]
+ * where (y0_b, x0_b) = tile_origins[2b], tile_origins[2b+1] when tile_origins is
+ * non-NULL and (0,0) otherwise.  A contiguous (B,3,H,W) torch tensor is
+ * {stride_b = 3HW, stride_c = HW, stride_y = W}; a sliding-window sweep over one
+ * slab uses stride_b = 0 and per-tile origins (sw_processing.py:151-163).
+ * Strides are in elements.  x origins, img_stride_y and the base pointer must
+ * keep every patch row 16-byte aligned (x0 % 4 == 0, stride_y % 4 == 0). */
+typedef struct ocm_vit_io {
+    const float *image;          /* dev */
+    int64_t img_stride_b, img_stride_c, img_stride_y;
+    const int32_t *tile_origins; /* dev, [batch][2] = (y0, x0), or NULL */
+    int32_t batch;               /* B                                               */
+    int32_t tile_h, tile_w;      /* pixels, multiples of patch_size                 */
+    const float *pos_embed;      /* dev, [N][D] fp32: row 0 = cls position, rows 1.. = (interpolated)
+                                    patch positions for this tile shape (:176-196)  */
+    int32_t flags;               /* OCM_OUT_* | OCM_LAST_ATTN_ONLY                  */
+    int32_t n_last;              /* n of get_intermediate_feat / get_intermediate_layers (>=1) */
+    float *out_feat;             /* dev, [n_last][B][N][D]            or NULL       */
+    float *out_attn;             /* dev, [n_last][B][H][N][N]         or NULL       */
+    float *out_qkv;              /* dev, [n_last][3][B][H][N][64]     or NULL       */
+    float *out_tokens;           /* dev, [B][N][D]                    or NULL       */
+    const int32_t *query_rows;   /* dev, [n_rows] token indices (0 = CLS) or NULL   */
+    int32_t n_rows;
+    int32_t reserved;
+    float *out_rows;             /* dev, [B][H][n_rows][N-1]          or NULL       */
+    void *workspace;             /* dev, >= ocm_vit_workspace_bytes(h, batch, N)    */
+    size_t workspace_bytes;
+    void *stream;                /* hipStream_t                                     */
+} ocm_vit_io;
+
+/* Bytes of scratch HBM one forward of `batch` tiles with `n_tokens` = N needs. */
+size_t ocm_vit_workspace_bytes(const ocm_vit_t *h, int32_t batch, int32_t n_tokens);
+
+/* VisionTransformer.get_intermediate_feat / get_last_selfattention / forward_feats /
+ * get_intermediate_layers (vision_transformer.py:211-256), selected by io->flags. */
+int ocm_vit_forward(ocm_vit_t *h, const ocm_vit_io *io);
+
+/* VisionTransformer.prepare_tokens (:198-209): patch embedding + cls + pos.
+ * Uses image/strides/origins/batch/tile_*, pos_embed and stream of `io`;
+ * writes x_out[B][N][D] fp32. */
+int ocm_vit_prepare_tokens(ocm_vit_t *h, const ocm_vit_io *io, float *x_out);
+
+/* Block.forward (:106-114) of block `index`, in place on x[B][N][D] fp32.
+ * flags: OCM_OUT_ATTN / OCM_OUT_QKV fill out_attn (B,H,N,N) / out_qkv (3,B,H,N,64);
+ * OCM_LAST_ATTN_ONLY returns after the probabilities (return_attention=True). */
+int ocm_vit_block_forward(ocm_vit_t *h, int32_t index, float *x, int32_t batch, int32_t n_tokens,
+                          int32_t flags, float *out_attn, float *out_qkv, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
+/* self.norm (:158, :214, :221, :234): y = LayerNorm(x) over rows of D, fp32 out. */
+int ocm_vit_final_norm(ocm_vit_t *h, const float *x, float *y, int64_t rows, void *stream);
+
+/* ---- stand-alone operators (kernel-level parity tests; same kernels the engine uses) ---- */
+
+/* nn.LayerNorm(D, eps) (:98,102,158). y is bf16 (out_bf16 != 0) or fp32. */
+int ocm_op_layernorm(const float *x, const float *gamma, const float *beta, void *y,
+                     int32_t out_bf16, int64_t rows, int32_t dim, float eps, void *stream);
+
+/* fp32 -> bf16 (round-to-nearest-even) of `count` elements. */
+int ocm_op_cast_bf16(const float *src, void *dst_bf16, size_t count, void *stream);
+
+enum {
+    OCM_EPI_BIAS_F32 = 0,       /* out fp32 [M][N] = acc + bias                                  */
+    OCM_EPI_BIAS_RESID_F32 = 1, /* out fp32 [M][N] = resid + acc + bias   (proj/fc2 + skip :110) */
+    OCM_EPI_BIAS_GELU_BF16 = 2, /* out bf16 [M][N] = gelu_erf(acc + bias) (fc1 + act :58-59)     */
+    OCM_EPI_BIAS_BF16 = 3       /* out bf16 [M][N] = acc + bias                                  */
+};
+/* nn.Linear: out = epilogue(A[M][K] · W[N][K]^T + bias[N]); A, W bf16 row-major,
+ * K % 64 == 0, N % 32 == 0. resid may alias out. */
+int ocm_op_linear(const void *a_bf16, const void *w_bf16, const float *bias, const float *resid,
+                  void *out, int32_t M, int32_t N, int32_t K, int32_t epilogue, void *stream);
+
+/* Head-major packed projections the attention kernels consume:
+ *   q, k : bf16 [B*H][n_pad][64];  vt : bf16 [B*H][64][n_pad],  n_pad = ocm_n_pad(N). */
+int32_t ocm_n_pad(int32_t n_tokens);
+
+/* Attention.forward qkv projection (:80): A[B*N][D] bf16 · Wqkv[3D][D]^T + b -> q/k/vt
+ * (and, when qkv_f32 != NULL, the fp32 (3,B,H,N,64) tensor the reference returns). */
+int ocm_op_qkv_proj(const void *a_bf16, const void *w_bf16, const float *bias, void *q, void *k,
+                    void *vt, float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads,
+                    void *stream);
+
+/* softmax(q k^T * scale) v (:83-87). ctx bf16 [B][N][H*64] (or NULL);
+ * lse2 fp32 [B*H][N] = log2-domain log-sum-exp of the scaled scores (or NULL). */
+int ocm_op_attention(const void *q, const void *k, const void *vt, void *ctx_bf16, float *lse2,
+                     int32_t batch, int32_t n_tokens, int32_t heads, float scale, void *stream);
+
+/* Attention probabilities (:83-84) from q, k and lse2: attn fp32 [B][H][N][N]. */
+int ocm_op_attention_probs(const void *q, const void *k, const float *lse2, float *attn,
+                           int32_t batch, int32_t n_tokens, int32_t heads, float scale,
+                           void *stream);
+
+/* Selected rows of the probabilities with the CLS column dropped
+ * (utils.py:232, attentions[0, :, query, 1:]): rows fp32 [B][H][n_rows][N-1]. */
+int ocm_op_attention_rows(const void *q, const void *k, const int32_t *query_rows, int32_t n_rows,
+                          float *rows, int32_t batch, int32_t n_tokens, int32_t heads, float scale,
+                          void *stream);
+
+/* compute_attention (utils.py:229-235) on device: attn fp32 [B][H][N][N] ->
+ * maps fp32 [H][hf*p][wf*p] = nearest-neighbour x p upsample of attn[b, :, query, 1:]. */
+int ocm_op_attention_map(const float *attn, float *maps, int32_t b, int32_t heads,
+                         int32_t n_tokens, int32_t query, int32_t hf, int32_t wf, int32_t p,
+                         void *stream);
+
+/* ---- sliding-window index math (host, integer; sw_processing.py:151-163) ---- */
+/* Number of windows per axis: len(range(0, size - 2*stride, stride)). */
+int32_t ocm_sw_count(int32_t size, int32_t stride);
+/* Row-major (y0, x0) origins for an (height x width) image; returns the number of
+ * windows written (<= cap) or a negative OCM_E* code. */
+int32_t ocm_sw_origins(int32_t height, int32_t width, int32_t stride, int32_t *origins_yx,
+                       int32_t cap);
+/* Contiguous block partition of `n_tiles` over `world` ranks:
+ * rank r owns [*begin, *end); every rank's padded share is ceil(n_tiles/world). */
+int32_t ocm_sw_shard(int32_t n_tiles, int32_t world, int32_t rank, int32_t *begin, int32_t *end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OCM_VIT_H */

@@ -1,0 +1,454 @@
+// engine.hip — the C ABI of include/ocm_vit.h: parameter store, workspace carving and the
+// launch sequence of one ViT forward (dino/vision_transformer.py:198-256 of the reference).
+// Host code only; every kernel lives in kernels_*.hip. Nothing here synchronises the device.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ocm_vit.h"
+#include "launch.h"
+
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail(OCM_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                                          __FILE__, __LINE__);                                    \
+    } while (0)
+
+extern "C" int ocm_abi_version(void) { return OCM_ABI_VERSION; }
+extern "C" const char *ocm_last_error(void) { return g_err.c_str(); }
+extern "C" int32_t ocm_n_pad(int32_t n_tokens) { return ocm_round_up(n_tokens, 8); }
+
+// ------------------------------------------------------------------------------------------
+// parameter store
+// ------------------------------------------------------------------------------------------
+enum ParamKind { P_F32, P_BF16, P_PATCH };
+struct Param {
+    std::string name;
+    ParamKind kind;
+    size_t count;   // elements in the reference tensor
+    size_t offset;  // bytes into the arena
+    bool set;
+};
+
+struct BlockP {
+    int ln1_g, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ln2_g, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b;
+};
+
+struct ocm_vit {
+    ocm_vit_config cfg;
+    int D, H, L, M, p, C, Kpe;
+    std::vector<Param> params;
+    std::vector<BlockP> blk;
+    int cls, pe_w, pe_b, norm_g, norm_b;
+    char *arena;
+    size_t arena_bytes;
+
+    int add(const std::string &name, ParamKind kind, size_t count, size_t stored_elems) {
+        Param pr{name, kind, count, arena_bytes, false};
+        const size_t bytes = stored_elems * (kind == P_F32 ? 4 : 2);
+        arena_bytes += (bytes + 255) & ~(size_t)255;
+        params.push_back(pr);
+        return (int)params.size() - 1;
+    }
+    template <class T>
+    T *ptr(int idx) const {
+        return (T *)(arena + params[idx].offset);
+    }
+};
+
+extern "C" int ocm_vit_create(const ocm_vit_config *cfg, ocm_vit_t **out) {
+    if (!cfg || !out) return fail(OCM_EINVAL, "ocm_vit_create: null argument");
+    const int D = cfg->embed_dim, H = cfg->num_heads, p = cfg->patch_size, C = cfg->in_chans;
+    if (D <= 0 || D % 64 || D > 1024) return fail(OCM_EINVAL, "embed_dim %d must be a multiple of 64, <= 1024", D);
+    if (H <= 0 || D != H * 64) return fail(OCM_EINVAL, "head_dim must be 64 (embed_dim %d, num_heads %d)", D, H);
+    if (p < 8 || p % 8 || p > 32) return fail(OCM_EINVAL, "patch_size %d must be 8, 16, 24 or 32", p);
+    if (C != 1 && C != 3) return fail(OCM_EINVAL, "in_chans %d must be 1 or 3", C);
+    if ((C * p * p) % 64) return fail(OCM_EINVAL, "in_chans*patch_size^2 = %d must be a multiple of 64", C * p * p);
+    if (cfg->mlp_hidden <= 0 || cfg->mlp_hidden % 64)
+        return fail(OCM_EINVAL, "mlp_hidden %d must be a multiple of 64", cfg->mlp_hidden);
+    if (cfg->depth <= 0) return fail(OCM_EINVAL, "depth %d must be positive", cfg->depth);
+    if (cfg->precision != OCM_PREC_BF16)
+        return fail(OCM_EINVAL, "precision %d is not implemented (only OCM_PREC_BF16)", cfg->precision);
+    ocm_vit *h = new ocm_vit();
+    h->cfg = *cfg;
+    h->D = D; h->H = H; h->L = cfg->depth; h->M = cfg->mlp_hidden; h->p = p; h->C = C; h->Kpe = C * p * p;
+    h->arena = nullptr;
+    h->arena_bytes = 0;
+    const size_t d = D, m = cfg->mlp_hidden;
+    h->cls = h->add("cls_token", P_F32, d, d);
+    // the reference conv weight is (D, C_ref, p, p); it is stored as bf16 [D][C*p*p] (C_ref folded if needed)
+    h->pe_w = h->add("patch_embed.proj.weight", P_PATCH, 0, d * h->Kpe);
+    h->pe_b = h->add("patch_embed.proj.bias", P_F32, d, d);
+    for (int i = 0; i < h->L; ++i) {
+        const std::string b = "blocks." + std::to_string(i) + ".";
+        BlockP bp;
+        bp.ln1_g = h->add(b + "norm1.weight", P_F32, d, d);
+        bp.ln1_b = h->add(b + "norm1.bias", P_F32, d, d);
+        bp.qkv_w = h->add(b + "attn.qkv.weight", P_BF16, 3 * d * d, 3 * d * d);
+        bp.qkv_b = h->add(b + "attn.qkv.bias", P_F32, 3 * d, 3 * d);
+        bp.proj_w = h->add(b + "attn.proj.weight", P_BF16, d * d, d * d);
+        bp.proj_b = h->add(b + "attn.proj.bias", P_F32, d, d);
+        bp.ln2_g = h->add(b + "norm2.weight", P_F32, d, d);
+        bp.ln2_b = h->add(b + "norm2.bias", P_F32, d, d);
+        bp.fc1_w = h->add(b + "mlp.fc1.weight", P_BF16, m * d, m * d);
+        bp.fc1_b = h->add(b + "mlp.fc1.bias", P_F32, m, m);
+        bp.fc2_w = h->add(b + "mlp.fc2.weight", P_BF16, d * m, d * m);
+        bp.fc2_b = h->add(b + "mlp.fc2.bias", P_F32, d, d);
+        h->blk.push_back(bp);
+    }
+    h->norm_g = h->add("norm.weight", P_F32, d, d);
+    h->norm_b = h->add("norm.bias", P_F32, d, d);
+    hipError_t e = hipMalloc((void **)&h->arena, h->arena_bytes);
+    if (e != hipSuccess) {
+        const size_t bytes = h->arena_bytes;
+        delete h;
+        return fail(OCM_ENOMEM, "hipMalloc(%zu) for parameters failed: %s", bytes, hipGetErrorString(e));
+    }
+    *out = h;
+    return OCM_OK;
+}
+
+extern "C" void ocm_vit_destroy(ocm_vit_t *h) {
+    if (!h) return;
+    if (h->arena) (void)hipFree(h->arena);
+    delete h;
+}
+
+extern "C" int ocm_vit_set_param(ocm_vit_t *h, const char *name, const float *dev_src, size_t count, void *stream) {
+    if (!h || !name || !dev_src) return fail(OCM_EINVAL, "ocm_vit_set_param: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    for (Param &pr : h->params) {
+        if (pr.name != name) continue;
+        char *dst = h->arena + pr.offset;
+        if (pr.kind == P_F32) {
+            if (count != pr.count) return fail(OCM_EINVAL, "%s: expected %zu elements, got %zu", name, pr.count, count);
+            HIP_TRY(hipMemcpyAsync(dst, dev_src, count * 4, hipMemcpyDeviceToDevice, s));
+        } else if (pr.kind == P_BF16) {
+            if (count != pr.count) return fail(OCM_EINVAL, "%s: expected %zu elements, got %zu", name, pr.count, count);
+            HIP_TRY(launch_cast_bf16(dev_src, (bf16 *)dst, count, s));
+        } else {  // conv weight (D, C_ref, p, p)
+            const size_t pp = (size_t)h->p * h->p, per = (size_t)h->D * pp;
+            if (count == 0 || count % per) return fail(OCM_EINVAL, "%s: %zu elements is not (D=%d, C, %d, %d)", name, count, h->D, h->p, h->p);
+            const int cref = (int)(count / per);
+            if (cref == h->C) {
+                HIP_TRY(launch_cast_bf16(dev_src, (bf16 *)dst, count, s));
+            } else if (h->C == 1) {  // grayscale fold: W_eff = W.sum(dim=1)
+                HIP_TRY(launch_fold_cast_bf16(dev_src, (bf16 *)dst, h->D, cref, (int)pp, s));
+            } else {
+                return fail(OCM_EINVAL, "%s: weight has %d input channels, engine was created with in_chans=%d", name, cref, h->C);
+            }
+        }
+        pr.set = true;
+        return OCM_OK;
+    }
+    return fail(OCM_ENAME, "unknown parameter '%s'", name);
+}
+
+extern "C" int ocm_vit_params_ready(const ocm_vit_t *h) {
+    if (!h) return fail(OCM_EINVAL, "null handle");
+    for (const Param &pr : h->params)
+        if (!pr.set) return fail(OCM_ESTATE, "parameter '%s' has not been set", pr.name.c_str());
+    return OCM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace
+// ------------------------------------------------------------------------------------------
+struct Workspace {
+    float *x;     // [T][D]   fp32 residual stream
+    bf16 *xn;     // [T][D]   LayerNorm output (GEMM A operand)
+    bf16 *q, *k;  // [B*H][n_pad][64]
+    bf16 *vt;     // [B*H][64][n_pad]
+    bf16 *ctx;    // [T][D]   attention output, heads merged
+    bf16 *hid;    // [T][M]   GELU(fc1)
+    float *lse;   // [B*H][N]
+    size_t bytes;
+};
+
+static Workspace carve(const ocm_vit *h, int batch, int n, char *base) {
+    Workspace w;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char *pch = base ? base + off : nullptr;
+        off += (bytes + 255) & ~(size_t)255;
+        return pch;
+    };
+    const size_t T = (size_t)batch * n, BH = (size_t)batch * h->H, np = ocm_n_pad(n);
+    w.x = (float *)take(T * h->D * 4);
+    w.xn = (bf16 *)take(T * h->D * 2);
+    w.q = (bf16 *)take(BH * np * 64 * 2);
+    w.k = (bf16 *)take(BH * np * 64 * 2);
+    w.vt = (bf16 *)take(BH * np * 64 * 2);
+    w.ctx = (bf16 *)take(T * h->D * 2);
+    w.hid = (bf16 *)take(T * h->M * 2);
+    w.lse = (float *)take(BH * n * 4);
+    w.bytes = off;
+    return w;
+}
+
+extern "C" size_t ocm_vit_workspace_bytes(const ocm_vit_t *h, int32_t batch, int32_t n_tokens) {
+    if (!h || batch <= 0 || n_tokens <= 1) return 0;
+    return carve(h, batch, n_tokens, nullptr).bytes;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward pieces
+// ------------------------------------------------------------------------------------------
+static int check_ws(const ocm_vit *h, int batch, int n, void *ws, size_t ws_bytes) {
+    if (!ws) return fail(OCM_ENOMEM, "workspace is null");
+    if ((uintptr_t)ws & 255) return fail(OCM_EINVAL, "workspace must be 256-byte aligned");
+    const size_t need = carve(h, batch, n, nullptr).bytes;
+    if (ws_bytes < need) return fail(OCM_ENOMEM, "workspace too small: %zu < %zu bytes", ws_bytes, need);
+    return OCM_OK;
+}
+
+// Block.forward (:106-114). x is updated in place unless attn_only.
+static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int batch, int n, bool attn_only,
+                     float *out_attn, float *out_qkv, const int32_t *query_rows, int n_rows, float *out_rows,
+                     hipStream_t s) {
+    const BlockP &bp = h->blk[i];
+    const int D = h->D, H = h->H, T = batch * n, np = ocm_n_pad(n);
+    const float eps = h->cfg.ln_eps, scale = h->cfg.qk_scale;
+    // y = attn(norm1(x))
+    HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, true, T, D, eps, s));
+    HIP_TRY(launch_qkv(w.xn, h->ptr<bf16>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, w.vt, out_qkv, batch, n, np, H, s));
+    if (out_rows) HIP_TRY(launch_attention_rows(w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s));
+    if (attn_only) {
+        if (out_attn) {
+            HIP_TRY(launch_attention(w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s));
+            HIP_TRY(launch_attention_probs(w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s));
+        }
+        return OCM_OK;
+    }
+    HIP_TRY(launch_attention(w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s));
+    if (out_attn) HIP_TRY(launch_attention_probs(w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s));
+    // x = x + proj(ctx)
+    HIP_TRY(launch_linear(w.ctx, h->ptr<bf16>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s));
+    // x = x + fc2(gelu(fc1(norm2(x))))
+    HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln2_g), h->ptr<float>(bp.ln2_b), w.xn, true, T, D, eps, s));
+    HIP_TRY(launch_linear(w.xn, h->ptr<bf16>(bp.fc1_w), h->ptr<float>(bp.fc1_b), nullptr, w.hid, T, h->M, D, OCM_EPI_BIAS_GELU_BF16, s));
+    HIP_TRY(launch_linear(w.hid, h->ptr<bf16>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s));
+    return OCM_OK;
+}
+
+static int check_tiles(const ocm_vit *h, const ocm_vit_io *io, int *n_out) {
+    if (!io) return fail(OCM_EINVAL, "io is null");
+    if (!io->image) return fail(OCM_EINVAL, "io->image is null");
+    if (!io->pos_embed) return fail(OCM_EINVAL, "io->pos_embed is null");
+    if (io->batch <= 0) return fail(OCM_EINVAL, "batch %d must be positive", io->batch);
+    if (io->tile_h <= 0 || io->tile_w <= 0 || io->tile_h % h->p || io->tile_w % h->p)
+        return fail(OCM_EINVAL, "tile %dx%d must be a positive multiple of patch_size %d", io->tile_h, io->tile_w, h->p);
+    if (io->img_stride_y % 4 || ((uintptr_t)io->image & 15) || io->img_stride_c % 4 || io->img_stride_b % 4)
+        return fail(OCM_EINVAL, "image base must be 16-byte aligned and strides multiples of 4 elements");
+    *n_out = (io->tile_h / h->p) * (io->tile_w / h->p) + 1;
+    return OCM_OK;
+}
+
+static int run_prepare(const ocm_vit *h, const ocm_vit_io *io, float *x, int n, hipStream_t s) {
+    PatchArgs pa{io->image, io->img_stride_b, io->img_stride_c, io->img_stride_y, io->tile_origins,
+                 io->batch, io->tile_h / h->p, io->tile_w / h->p, h->p, h->C};
+    HIP_TRY(launch_cls_rows(h->ptr<float>(h->cls), io->pos_embed, x, io->batch, n, h->D, s));
+    HIP_TRY(launch_patch_embed(pa, h->ptr<bf16>(h->pe_w), h->ptr<float>(h->pe_b), io->pos_embed, x, h->D, s));
+    return OCM_OK;
+}
+
+extern "C" int ocm_vit_prepare_tokens(ocm_vit_t *h, const ocm_vit_io *io, float *x_out) {
+    if (!h || !x_out) return fail(OCM_EINVAL, "null argument");
+    int rc = ocm_vit_params_ready(h);
+    if (rc) return rc;
+    int n = 0;
+    if ((rc = check_tiles(h, io, &n))) return rc;
+    return run_prepare(h, io, x_out, n, (hipStream_t)io->stream);
+}
+
+extern "C" int ocm_vit_block_forward(ocm_vit_t *h, int32_t index, float *x, int32_t batch, int32_t n_tokens,
+                                     int32_t flags, float *out_attn, float *out_qkv, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+    if (!h || !x) return fail(OCM_EINVAL, "null argument");
+    if (index < 0 || index >= h->L) return fail(OCM_EINVAL, "block index %d out of range [0,%d)", index, h->L);
+    if (batch <= 0 || n_tokens <= 1) return fail(OCM_EINVAL, "bad shape batch=%d n_tokens=%d", batch, n_tokens);
+    int rc = ocm_vit_params_ready(h);
+    if (rc) return rc;
+    if ((rc = check_ws(h, batch, n_tokens, workspace, workspace_bytes))) return rc;
+    if ((flags & OCM_OUT_ATTN) && !out_attn) return fail(OCM_EINVAL, "OCM_OUT_ATTN without out_attn");
+    if ((flags & OCM_OUT_QKV) && !out_qkv) return fail(OCM_EINVAL, "OCM_OUT_QKV without out_qkv");
+    const Workspace w = carve(h, batch, n_tokens, (char *)workspace);
+    return run_block(h, index, w, x, batch, n_tokens, (flags & OCM_LAST_ATTN_ONLY) != 0,
+                     (flags & OCM_OUT_ATTN) ? out_attn : nullptr, (flags & OCM_OUT_QKV) ? out_qkv : nullptr, nullptr, 0,
+                     nullptr, (hipStream_t)stream);
+}
+
+extern "C" int ocm_vit_final_norm(ocm_vit_t *h, const float *x, float *y, int64_t rows, void *stream) {
+    if (!h || !x || !y) return fail(OCM_EINVAL, "null argument");
+    int rc = ocm_vit_params_ready(h);
+    if (rc) return rc;
+    HIP_TRY(launch_layernorm(x, h->ptr<float>(h->norm_g), h->ptr<float>(h->norm_b), y, false, rows, h->D, h->cfg.ln_eps,
+                             (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_vit_forward(ocm_vit_t *h, const ocm_vit_io *io) {
+    if (!h) return fail(OCM_EINVAL, "null handle");
+    int rc = ocm_vit_params_ready(h);
+    if (rc) return rc;
+    int n = 0;
+    if ((rc = check_tiles(h, io, &n))) return rc;
+    const int fl = io->flags, B = io->batch, L = h->L;
+    const bool attn_only = fl & OCM_LAST_ATTN_ONLY;
+    if (io->n_last < 1 || io->n_last > L) return fail(OCM_EINVAL, "n_last %d out of range [1,%d]", io->n_last, L);
+    if (attn_only && (fl & (OCM_OUT_FEAT | OCM_OUT_TOKENS | OCM_OUT_QKV)))
+        return fail(OCM_EINVAL, "OCM_LAST_ATTN_ONLY excludes FEAT/TOKENS/QKV outputs");
+    if (attn_only && io->n_last != 1) return fail(OCM_EINVAL, "OCM_LAST_ATTN_ONLY requires n_last == 1");
+    if ((fl & OCM_OUT_FEAT) && !io->out_feat) return fail(OCM_EINVAL, "OCM_OUT_FEAT without out_feat");
+    if ((fl & OCM_OUT_ATTN) && !io->out_attn) return fail(OCM_EINVAL, "OCM_OUT_ATTN without out_attn");
+    if ((fl & OCM_OUT_QKV) && !io->out_qkv) return fail(OCM_EINVAL, "OCM_OUT_QKV without out_qkv");
+    if ((fl & OCM_OUT_TOKENS) && !io->out_tokens) return fail(OCM_EINVAL, "OCM_OUT_TOKENS without out_tokens");
+    if ((fl & OCM_OUT_ROWS) && (!io->out_rows || io->n_rows <= 0))
+        return fail(OCM_EINVAL, "OCM_OUT_ROWS needs out_rows and n_rows > 0");
+    if ((rc = check_ws(h, B, n, io->workspace, io->workspace_bytes))) return rc;
+    hipStream_t s = (hipStream_t)io->stream;
+    const Workspace w = carve(h, B, n, (char *)io->workspace);
+    if ((rc = run_prepare(h, io, w.x, n, s))) return rc;
+    const size_t T = (size_t)B * n;
+    for (int i = 0; i < L; ++i) {
+        const int slot = i - (L - io->n_last);  // >= 0 for the returned blocks
+        const bool ret = slot >= 0, last = i == L - 1;
+        float *oa = (ret && (fl & OCM_OUT_ATTN)) ? io->out_attn + (size_t)slot * B * h->H * n * n : nullptr;
+        float *oq = (ret && (fl & OCM_OUT_QKV)) ? io->out_qkv + (size_t)slot * 3 * B * h->H * n * 64 : nullptr;
+        float *orow = (last && (fl & OCM_OUT_ROWS)) ? io->out_rows : nullptr;
+        if ((rc = run_block(h, i, w, w.x, B, n, attn_only && last, oa, oq, io->query_rows, io->n_rows, orow, s)))
+            return rc;
+        if (ret && (fl & OCM_OUT_FEAT))
+            HIP_TRY(launch_layernorm(w.x, h->ptr<float>(h->norm_g), h->ptr<float>(h->norm_b),
+                                     io->out_feat + (size_t)slot * T * h->D, false, T, h->D, h->cfg.ln_eps, s));
+    }
+    if (fl & OCM_OUT_TOKENS)
+        HIP_TRY(hipMemcpyAsync(io->out_tokens, w.x, T * h->D * 4, hipMemcpyDeviceToDevice, s));
+    return OCM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// stand-alone operators
+// ------------------------------------------------------------------------------------------
+extern "C" int ocm_op_layernorm(const float *x, const float *gamma, const float *beta, void *y, int32_t out_bf16,
+                                int64_t rows, int32_t dim, float eps, void *stream) {
+    if (!x || !gamma || !beta || !y) return fail(OCM_EINVAL, "null argument");
+    if (dim <= 0 || dim % 2 || dim > 1024) return fail(OCM_EINVAL, "dim %d must be even and <= 1024", dim);
+    HIP_TRY(launch_layernorm(x, gamma, beta, y, out_bf16 != 0, rows, dim, eps, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_cast_bf16(const float *src, void *dst, size_t count, void *stream) {
+    if (!src || !dst) return fail(OCM_EINVAL, "null argument");
+    HIP_TRY(launch_cast_bf16(src, (bf16 *)dst, count, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_linear(const void *a, const void *w, const float *bias, const float *resid, void *out,
+                             int32_t M, int32_t N, int32_t K, int32_t epilogue, void *stream) {
+    if (!a || !w || !out) return fail(OCM_EINVAL, "null argument");
+    if (M <= 0 || N <= 0 || N % 32 || K <= 0 || K % 64) return fail(OCM_EINVAL, "bad shape M=%d N=%d K=%d (N%%32, K%%64)", M, N, K);
+    if (epilogue < 0 || epilogue > 3) return fail(OCM_EINVAL, "bad epilogue %d", epilogue);
+    if (epilogue == OCM_EPI_BIAS_RESID_F32 && !resid) return fail(OCM_EINVAL, "residual epilogue without resid");
+    HIP_TRY(launch_linear((const bf16 *)a, (const bf16 *)w, bias, resid, out, M, N, K, epilogue, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_qkv_proj(const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
+                               float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads, void *stream) {
+    if (!a || !w || !bias || !q || !k || !vt) return fail(OCM_EINVAL, "null argument");
+    if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
+    HIP_TRY(launch_qkv((const bf16 *)a, (const bf16 *)w, bias, (bf16 *)q, (bf16 *)k, (bf16 *)vt, qkv_f32, batch, n_tokens,
+                       ocm_n_pad(n_tokens), heads, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_attention(const void *q, const void *k, const void *vt, void *ctx, float *lse2, int32_t batch,
+                                int32_t n_tokens, int32_t heads, float scale, void *stream) {
+    if (!q || !k || !vt) return fail(OCM_EINVAL, "null argument");
+    if (!ctx && !lse2) return fail(OCM_EINVAL, "nothing to compute: ctx and lse2 are both null");
+    if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
+    HIP_TRY(launch_attention((const bf16 *)q, (const bf16 *)k, (const bf16 *)vt, (bf16 *)ctx, lse2, batch, n_tokens,
+                             ocm_n_pad(n_tokens), heads, scale, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_attention_probs(const void *q, const void *k, const float *lse2, float *attn, int32_t batch,
+                                      int32_t n_tokens, int32_t heads, float scale, void *stream) {
+    if (!q || !k || !lse2 || !attn) return fail(OCM_EINVAL, "null argument");
+    if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
+    HIP_TRY(launch_attention_probs((const bf16 *)q, (const bf16 *)k, lse2, attn, batch, n_tokens, ocm_n_pad(n_tokens),
+                                   heads, scale, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_attention_rows(const void *q, const void *k, const int32_t *query_rows, int32_t n_rows,
+                                     float *rows, int32_t batch, int32_t n_tokens, int32_t heads, float scale,
+                                     void *stream) {
+    if (!q || !k || !rows) return fail(OCM_EINVAL, "null argument");
+    if (batch <= 0 || n_tokens <= 1 || heads <= 0 || n_rows <= 0) return fail(OCM_EINVAL, "bad shape");
+    HIP_TRY(launch_attention_rows((const bf16 *)q, (const bf16 *)k, query_rows, n_rows, rows, batch, n_tokens,
+                                  ocm_n_pad(n_tokens), heads, scale, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_attention_map(const float *attn, float *maps, int32_t b, int32_t heads, int32_t n_tokens,
+                                    int32_t query, int32_t hf, int32_t wf, int32_t p, void *stream) {
+    if (!attn || !maps) return fail(OCM_EINVAL, "null argument");
+    if (hf * wf + 1 != n_tokens) return fail(OCM_EINVAL, "hf*wf+1 = %d != n_tokens %d", hf * wf + 1, n_tokens);
+    if (query < 0 || query >= n_tokens) return fail(OCM_EINVAL, "query %d out of range", query);
+    HIP_TRY(launch_attention_map(attn, maps, b, heads, n_tokens, query, hf, wf, p, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sliding-window index math (integers, host) — sw_processing.py:151-163 and SURVEY §8-e
+// ------------------------------------------------------------------------------------------
+extern "C" int32_t ocm_sw_count(int32_t size, int32_t stride) {
+    if (stride <= 0) return 0;
+    const int32_t stop = size - 2 * stride;  // range(0, size - 2*stride, stride)
+    return stop <= 0 ? 0 : (stop + stride - 1) / stride;
+}
+
+extern "C" int32_t ocm_sw_origins(int32_t height, int32_t width, int32_t stride, int32_t *origins_yx, int32_t cap) {
+    if (!origins_yx || stride <= 0) return -OCM_EINVAL;
+    // NB the reference unpacks `height, width = image.size` from a PIL (width, height) pair and
+    // loops y over the first, x over the second (sw_processing.py:153-157); for the square images
+    // it is used on the two agree. Here y walks `height`, x walks `width`.
+    const int32_t ny = ocm_sw_count(height, stride), nx = ocm_sw_count(width, stride);
+    if ((int64_t)ny * nx > cap) return -OCM_ENOMEM;
+    int32_t n = 0;
+    for (int32_t iy = 0; iy < ny; ++iy)
+        for (int32_t ix = 0; ix < nx; ++ix) {
+            origins_yx[2 * n] = iy * stride;
+            origins_yx[2 * n + 1] = ix * stride;
+            ++n;
+        }
+    return n;
+}
+
+extern "C" int32_t ocm_sw_shard(int32_t n_tiles, int32_t world, int32_t rank, int32_t *begin, int32_t *end) {
+    if (world <= 0 || rank < 0 || rank >= world || n_tiles < 0 || !begin || !end) return -OCM_EINVAL;
+    const int32_t share = (n_tiles + world - 1) / world;
+    int32_t b = rank * share, e = b + share;
+    if (b > n_tiles) b = n_tiles;
+    if (e > n_tiles) e = n_tiles;
+    *begin = b;
+    *end = e;
+    return share;
+}

@@ -1,0 +1,144 @@
+// gemm_core.h — bf16 MFMA tile GEMM for the ViT projections (gfx950).
+//
+//   C[m][n] = sum_k A[m][k] * W[n][k]        (nn.Linear layout: W is [N][K], K contiguous)
+//
+// One workgroup = WAVES_M x WAVES_N wavefronts computes a BM x BN tile with
+// v_mfma_f32_32x32x16_bf16; K is walked in 64-wide steps through a double-buffered,
+// XOR-swizzled LDS image (common.h: lds_off).  Staging is register-staged with the
+// issue-early / write-late split: the global loads of K-step t+1 are issued before the
+// MFMAs of step t and committed to the other LDS buffer after them, one barrier per step.
+//
+// The A operand comes through a loader policy so the same main loop serves
+//   - plain bf16 activations (RowLoader) and
+//   - the im2col-free patch gather from fp32 image planes (PatchLoader, kernels_gemm.hip).
+// The accumulator can be produced transposed (SWAP): acc^T has the token index on the
+// lanes, which is how the V projection is written key-contiguous (V^T) with coalesced stores.
+#pragma once
+#include "common.h"
+
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
+struct GemmCfg {
+    static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
+    static constexpr int NT = WAVES_M * WAVES_N * OCM_WAVE;
+    static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    static constexpr int TM = WM / 32, TN = WN / 32;
+    static constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;  // 16-B chunks / thread / K-step
+    static constexpr int LDS_BYTES = 2 * (BM + BN) * 128;
+    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
+    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging must divide evenly");
+};
+
+// A operand = bf16 row-major activations.
+struct RowLoader {
+    const bf16 *A;
+    int64_t lda;
+    typedef const bf16 *Handle;
+    typedef bf16x8 Raw;
+    __device__ __forceinline__ Handle row(int m) const { return A + (int64_t)m * lda; }
+    __device__ __forceinline__ Raw load(Handle h, int k) const { return *(const bf16x8 *)(h + k); }
+    __device__ __forceinline__ static bf16x8 finish(const Raw &r) { return r; }
+};
+
+// Main loop. acc[i][j] is the 32x32 tile at rows wm*WM+32i, cols wn*WN+32j of the block
+// tile; with SWAP the register/lane roles of that tile are transposed (lane = row m).
+template <class Cfg, bool SWAP, class ALoad>
+__device__ __forceinline__ void gemm_mainloop(const ALoad &al, const bf16 *__restrict__ W, int64_t ldw,
+                                              int m0, int n0, int M, int N, int K, char *smem,
+                                              f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
+    constexpr int A_CH = Cfg::A_CH, B_CH = Cfg::B_CH, TM = Cfg::TM, TN = Cfg::TN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int r = lane & 31, h = lane >> 5;
+    char *As = smem;
+    char *Bs = smem + 2 * BM * 128;
+
+    typename ALoad::Handle a_h[A_CH];
+    const bf16 *b_h[B_CH];
+    int a_off[A_CH], b_off[B_CH], a_k[A_CH], b_k[B_CH];
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) {
+        const int q = tid + NT * i, row = q >> 3, c = q & 7;
+        a_h[i] = al.row(min(m0 + row, M - 1));
+        a_off[i] = lds_off(row, c);
+        a_k[i] = c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) {
+        const int q = tid + NT * i, row = q >> 3, c = q & 7;
+        b_h[i] = W + (int64_t)min(n0 + row, N - 1) * ldw;
+        b_off[i] = lds_off(row, c);
+        b_k[i] = c * 8;
+    }
+
+    typename ALoad::Raw ra[A_CH];
+    bf16x8 rb[B_CH];
+    auto issue = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) ra[i] = al.load(a_h[i], k0 + a_k[i]);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) rb[i] = *(const bf16x8 *)(b_h[i] + k0 + b_k[i]);
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) *(bf16x8 *)(As + buf * BM * 128 + a_off[i]) = ALoad::finish(ra[i]);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) *(bf16x8 *)(Bs + buf * BN * 128 + b_off[i]) = rb[i];
+    };
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nt = K >> 6;
+    issue(0);
+    commit(0);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) issue((t + 1) << 6);
+        const char *Ab = As + buf * BM * 128 + (wm * Cfg::WM) * 128;
+        const char *Bb = Bs + buf * BN * 128 + (wn * Cfg::WN) * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a[TM], b[TN];
+            // rows wm*WM + 32i + r: the swizzle term (row>>1)&7 only depends on r because
+            // the wave/tile row offsets are multiples of 32.
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8 *)(Ab + i * 32 * 128 + lds_off(r, 2 * s + h));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8 *)(Bb + j * 32 * 128 + lds_off(r, 2 * s + h));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = SWAP ? mfma32(b[j], a[i], acc[i][j]) : mfma32(a[i], b[j], acc[i][j]);
+        }
+        if (t + 1 < nt) commit(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// Generic kernel: grid = tiles_m * tiles_n workgroups (linear, XCD-remapped so the
+// workgroups that share an A row panel sit on one XCD's L2).
+template <class Cfg, bool SWAP, class ALoad, class Epi>
+__global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const bf16 *__restrict__ W, int64_t ldw,
+                                                       int M, int N, int K, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = id / tiles_n, tn = id - tm * tiles_n;
+    const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+    f32x16 acc[Cfg::TM][Cfg::TN];
+    gemm_mainloop<Cfg, SWAP>(al, W, ldw, m0, n0, M, N, K, smem, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j)
+            epi(acc[i][j], m0 + wm * Cfg::WM + 32 * i, n0 + wn * Cfg::WN + 32 * j, lane);
+}

@@ -1,0 +1,340 @@
+// kernels_attn.hip — multi-head self-attention with per-head attention-map extraction.
+// Reference arithmetic: Attention.forward, dino/vision_transformer.py:83-87
+//     attn = softmax((q @ k^T) * scale);  x = attn @ v
+// and the consumers of its rows, utils.py:229-235 (compute_attention).
+//
+// Layouts (produced by the qkv GEMM epilogue, kernels_gemm.hip):
+//     q, k : bf16 [B*H][n_pad][64]      (head_dim contiguous)
+//     vt   : bf16 [B*H][64][n_pad]      (key index contiguous = V^T)
+// head_dim is 64 for ViT-T/S/B.
+//
+// attn_fwd_kernel — flash-style: one wavefront owns 32 query rows, the workgroup's 4 waves
+//   share 64-key K / V^T tiles staged through double-buffered swizzled LDS. Scores are computed
+//   TRANSPOSED (S^T = K·Q^T, keys in registers, query on the lane) so that
+//     * the row max / row sum are in-register reductions plus one lane<->lane+32 exchange, and
+//     * the exponentiated tile is already the B operand of O^T += V^T·P^T (no LDS round trip):
+//       K rows are fed in the order pi(r) (bits 2,3 of r swapped) which makes registers
+//       8s..8s+7 of the accumulator hold keys 16s+8h..16s+8h+7, i.e. the MFMA k order.
+//   Softmax is online (running max / sum, fp32, exp2 domain); P never touches HBM.
+//   Optionally emits lse2[row] = max + log2(sum) so the probabilities can be re-materialised.
+//
+// attn_probs_kernel — the (B,H,N,N) fp32 probabilities the reference returns: recomputes
+//   S = Q·K^T with the KEY on the lane, so each store instruction writes 32 consecutive
+//   floats of one row; p = exp2(s*scale*log2e - lse2[row]).
+//
+// attn_rows_kernel — only selected query rows with the CLS column dropped (what
+//   compute_attention consumes): one wavefront per (row, b, h), fp32 dot products.
+#include "launch.h"
+
+#define LOG2E 1.4426950408889634f
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// key held by accumulator register `reg` of lane half `h` when K rows are loaded in pi order
+__device__ __forceinline__ int key_of_reg(int reg, int h) {
+    return (reg & 3) + 4 * ((reg >> 2) & 1) + 8 * h + 16 * (reg >> 3);
+}
+__device__ __forceinline__ int pi_row(int r) {  // swap bits 2 and 3
+    return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+}
+
+template <bool WANT_O>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ Q, const bf16 *__restrict__ Kk,
+                                                       const bf16 *__restrict__ Vt, bf16 *__restrict__ ctx,
+                                                       float *__restrict__ lse2, int N, int npad, int H,
+                                                       float scale2) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 128];  // K[2] | Vt[2], 8 KiB each
+    char *Ks = smem, *Vs = smem + 2 * 64 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bool active = q0 < N;  // wave-uniform
+    const bf16 *Qb = Q + (int64_t)bh * npad * 64;
+    const bf16 *Kb = Kk + (int64_t)bh * npad * 64;
+    const bf16 *Vb = Vt + (int64_t)bh * 64 * npad;
+
+    // Q^T as the B operand: lane (query r, half h) holds Q[q0+r][16s + 8h .. +7]
+    bf16x8 qf[4];
+    {
+        const int qrow = min(q0 + r, N - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8 *)(Qb + (int64_t)qrow * 64 + 16 * s + 8 * h);
+    }
+
+    // staging: 512 K chunks + 512 V^T chunks of 16 B per tile, 256 threads -> 2 + 2 each
+    bf16x8 rk[2], rv[2];
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qd = tid + 256 * i, row = qd >> 3, c = qd & 7;
+            const int key = min(kt * 64 + row, N - 1);
+            rk[i] = *(const bf16x8 *)(Kb + (int64_t)key * 64 + c * 8);
+            const int key0 = kt * 64 + c * 8;  // V^T row = d, chunk = 8 keys
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            if (key0 < npad) {
+                v = *(const bf16x8 *)(Vb + (int64_t)row * npad + key0);
+                if (key0 + 8 > N) {  // keys >= N are padding: force exact zeros (0 * garbage must not be NaN)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (key0 + e >= N) v[e] = (bf16)0.f;
+                }
+            }
+            rv[i] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int qd = tid + 256 * i, row = qd >> 3, c = qd & 7;
+            *(bf16x8 *)(Ks + buf * 8192 + lds_off(row, c)) = rk[i];
+            *(bf16x8 *)(Vs + buf * 8192 + lds_off(row, c)) = rv[i];
+        }
+    };
+
+    f32x16 O[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[0][e] = O[1][e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int pr = pi_row(r);
+    const int ntiles = (N + 63) >> 6;
+
+    issue(0);
+    commit(0);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles) issue(kt + 1);
+        if (active) {
+            const char *Kt = Ks + buf * 8192, *Vtile = Vs + buf * 8192;
+            f32x16 S[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) S[sub][e] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bf16x8 a = *(const bf16x8 *)(Kt + sub * 32 * 128 + lds_off(pr, 2 * s + h));
+                    S[sub] = mfma32(a, qf[s], S[sub]);
+                }
+            }
+            float mx = -INFINITY;
+            const bool tail = (kt + 1) * 64 > N;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = S[sub][e] * scale2;
+                    if (tail && kt * 64 + sub * 32 + key_of_reg(e, h) >= N) v = -INFINITY;
+                    S[sub][e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);  // finite: every tile holds at least one valid key
+            const float alpha = fast_exp2(m - mn);
+            m = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = fast_exp2(S[sub][e] - mn);
+                    S[sub][e] = p;
+                    ps += p;
+                }
+            l = l * alpha + ps;
+            if (WANT_O) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    O[0][e] *= alpha;
+                    O[1][e] *= alpha;
+                }
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        bf16x8 pb;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pb[e] = (bf16)S[sub][8 * s2 + e];
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const bf16x8 a =
+                                *(const bf16x8 *)(Vtile + db * 32 * 128 + lds_off(r, 4 * sub + 2 * s2 + h));
+                            O[db] = mfma32(a, pb, O[db]);
+                        }
+                    }
+            }
+        }
+        if (kt + 1 < ntiles) commit(buf ^ 1);
+        __syncthreads();
+    }
+
+    if (!active) return;
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const int qrow = q0 + r;
+    if (qrow < N) {
+        if (lse2 && h == 0) lse2[(int64_t)bh * N + qrow] = m + __log2f(lt);
+        if (WANT_O) {
+            const float inv = 1.0f / lt;
+            const int b = bh / H, head = bh - b * H;
+            bf16 *dst = ctx + ((int64_t)b * N + qrow) * (H * 64) + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(O[db][4 * g + e] * inv);
+                    *(bf16x4 *)(dst + db * 32 + 8 * g + 4 * h) = o;
+                }
+        }
+    }
+}
+
+hipError_t launch_attention(const bf16 *q, const bf16 *k, const bf16 *vt, bf16 *ctx, float *lse2, int batch,
+                            int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
+    const int qtiles = (n_tokens + 31) / 32;
+    const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
+    if (ctx)
+        attn_fwd_kernel<true><<<grid, block, 0, s>>>(q, k, vt, ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+    else
+        attn_fwd_kernel<false><<<grid, block, 0, s>>>(q, k, vt, ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_probs_kernel(const bf16 *__restrict__ Q, const bf16 *__restrict__ Kk,
+                                                         const float *__restrict__ lse2, float *__restrict__ attn,
+                                                         int N, int npad, float scale2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= N) return;  // no barriers in this kernel
+    const bf16 *Qb = Q + (int64_t)bh * npad * 64;
+    const bf16 *Kb = Kk + (int64_t)bh * npad * 64;
+    bf16x8 qf[4];
+    {
+        const int qrow = min(q0 + r, N - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8 *)(Qb + (int64_t)qrow * 64 + 16 * s + 8 * h);
+    }
+    float lr[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lr[e] = lse2[(int64_t)bh * N + min(q0 + acc_row32(e, h), N - 1)];
+    float *out = attn + (int64_t)bh * N * N;
+    const int ktiles = (N + 31) >> 5;
+    bf16x8 kf[4], kn[4];
+    auto loadk = [&](int kt, bf16x8(&dst)[4]) {
+        const int key = min(kt * 32 + r, N - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dst[s] = *(const bf16x8 *)(Kb + (int64_t)key * 64 + 16 * s + 8 * h);
+    };
+    loadk(0, kf);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        if (kt + 1 < ktiles) loadk(kt + 1, kn);
+        f32x16 S;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) S = mfma32(qf[s], kf[s], S);  // rows = queries, col (lane) = key
+        const int key = kt * 32 + r;
+        if (key < N) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qrow = q0 + acc_row32(e, h);
+                if (qrow < N) out[(int64_t)qrow * N + key] = fast_exp2(S[e] * scale2 - lr[e]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[s] = kn[s];
+    }
+}
+
+hipError_t launch_attention_probs(const bf16 *q, const bf16 *k, const float *lse2, float *attn, int batch,
+                                  int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
+    const int qtiles = (n_tokens + 31) / 32;
+    const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
+    attn_probs_kernel<<<grid, block, 0, s>>>(q, k, lse2, attn, n_tokens, n_pad, scale * LOG2E);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// rows[b][h][i][j-1] = softmax_j(q[query_i] . k[j] * scale), j = 1..N-1   (utils.py:232)
+__global__ __launch_bounds__(64) void attn_rows_kernel(const bf16 *__restrict__ Q, const bf16 *__restrict__ Kk,
+                                                       const int32_t *__restrict__ query_rows, int n_rows,
+                                                       float *__restrict__ rows, int N, int npad, float scale2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *sc = (float *)smem;  // N scores
+    const int lane = threadIdx.x, bh = blockIdx.y, qi = blockIdx.x;
+    const int query = query_rows ? query_rows[qi] : 0;
+    const bf16 *qp = Q + ((int64_t)bh * npad + query) * 64;
+    float qv[64];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const bf16x8 t = *(const bf16x8 *)(qp + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[c * 8 + e] = (float)t[e];
+    }
+    float mx = -INFINITY;
+    for (int key = lane; key < N; key += 64) {
+        const bf16 *kp = Kk + ((int64_t)bh * npad + key) * 64;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const bf16x8 t = *(const bf16x8 *)(kp + c * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc = fmaf(qv[c * 8 + e], (float)t[e], acc);
+        }
+        acc *= scale2;
+        sc[key] = acc;
+        mx = fmaxf(mx, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int key = lane; key < N; key += 64) {
+        const float p = fast_exp2(sc[key] - mx);
+        sc[key] = p;
+        sum += p;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.0f / sum;
+    float *dst = rows + ((int64_t)bh * n_rows + qi) * (N - 1);
+    for (int key = 1 + lane; key < N; key += 64) dst[key - 1] = sc[key] * inv;
+}
+
+hipError_t launch_attention_rows(const bf16 *q, const bf16 *k, const int32_t *query_rows, int n_rows, float *rows,
+                                 int batch, int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
+    if (n_rows <= 0) return hipSuccess;
+    const dim3 grid(n_rows, batch * heads), block(64);
+    attn_rows_kernel<<<grid, block, (size_t)n_tokens * sizeof(float), s>>>(q, k, query_rows, n_rows, rows, n_tokens,
+                                                                           n_pad, scale * LOG2E);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// compute_attention (utils.py:229-235): attentions[b, :, query, 1:] -> (H, hf, wf) -> nearest x p.
+// Token 1 + y*wf + x is patch (y, x): row-major flatten of the conv output (:131).
+__global__ __launch_bounds__(256) void attn_map_kernel(const float *__restrict__ attn, float *__restrict__ maps,
+                                                       int b, int H, int N, int query, int hf, int wf, int p) {
+    const int W = wf * p, Hh = hf * p;
+    const int64_t total = (int64_t)H * Hh * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W), y = (int)((i / W) % Hh), head = (int)(i / ((int64_t)W * Hh));
+        const int tok = 1 + (y / p) * wf + (x / p);
+        maps[i] = attn[(((int64_t)b * H + head) * N + query) * N + tok];
+    }
+}
+
+hipError_t launch_attention_map(const float *attn, float *maps, int b, int heads, int n_tokens, int query, int hf,
+                                int wf, int p, hipStream_t s) {
+    const int64_t total = (int64_t)heads * hf * p * wf * p;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    attn_map_kernel<<<dim3(blocks), dim3(256), 0, s>>>(attn, maps, b, heads, n_tokens, query, hf, wf, p);
+    return hipGetLastError();
+}

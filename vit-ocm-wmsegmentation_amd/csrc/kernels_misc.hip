@@ -1,0 +1,131 @@
+// kernels_misc.hip — HBM-bound row kernels: LayerNorm, fp32->bf16 casts, cls rows.
+#include "launch.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// nn.LayerNorm(D, eps) — reference: dino/vision_transformer.py:98,102,158 (eps 1e-6 via :262-278).
+// One wavefront per row; the row lives in registers (float2 per lane per 128 columns), mean and
+// biased variance are two in-register passes (same two-pass form as ATen's CPU kernel), fp32
+// statistics. Output is bf16 (operand of the next MFMA GEMM) or fp32 (final norm -> feat).
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, void *__restrict__ y,
+                                                        int64_t rows, int dim, float eps) {
+    constexpr int MAXV = 8;  // dim <= 1024
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * dim;
+    f32x2 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 2 + i * 128;
+        if (c < dim) {
+            v[i] = *(const f32x2 *)(xr + c);
+            s += v[i][0] + v[i][1];
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 2 + i * 128;
+        if (c < dim) {
+            const float a = v[i][0] - mean, b = v[i][1] - mean;
+            q += a * a + b * b;
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)dim + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = lane * 2 + i * 128;
+        if (c < dim) {
+            const f32x2 g = *(const f32x2 *)(gamma + c), b = *(const f32x2 *)(beta + c);
+            const float o0 = (v[i][0] - mean) * rstd * g[0] + b[0];
+            const float o1 = (v[i][1] - mean) * rstd * g[1] + b[1];
+            if (OUT_BF16) {
+                bf16x2 o;
+                o[0] = (bf16)o0;
+                o[1] = (bf16)o1;
+                *(bf16x2 *)((bf16 *)y + row * dim + c) = o;
+            } else {
+                f32x2 o = {o0, o1};
+                *(f32x2 *)((float *)y + row * dim + c) = o;
+            }
+        }
+    }
+}
+
+hipError_t launch_layernorm(const float *x, const float *gamma, const float *beta, void *y, bool out_bf16,
+                            int64_t rows, int dim, float eps, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (out_bf16)
+        layernorm_kernel<true><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, dim, eps);
+    else
+        layernorm_kernel<false><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, dim, eps);
+    return hipGetLastError();
+}
+
+// fp32 -> bf16 RNE (v_cvt_pk_bf16_f32), 8 elements per thread, grid-stride.
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float *__restrict__ src, bf16 *__restrict__ dst,
+                                                        size_t count) {
+    const size_t nvec = count >> 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 a = *(const f32x4 *)(src + i * 8), b = *(const f32x4 *)(src + i * 8 + 4);
+        *(bf16x8 *)(dst + i * 8) = cvt8(a, b);
+    }
+    // tail (count % 8) by the first threads of block 0
+    if (blockIdx.x == 0) {
+        const size_t t = (nvec << 3) + threadIdx.x;
+        if (t < count) dst[t] = (bf16)src[t];
+    }
+}
+
+hipError_t launch_cast_bf16(const float *src, bf16 *dst, size_t count, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    size_t blocks = ((count >> 3) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    cast_bf16_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(src, dst, count);
+    return hipGetLastError();
+}
+
+// Grayscale fold of the patch-embedding conv weight: for R==G==B inputs
+// conv(x, W) == conv(x[:, :1], W.sum(dim=1)). src (D, C, pp) fp32 -> dst (D, pp) bf16.
+__global__ __launch_bounds__(256) void fold_cast_kernel(const float *__restrict__ src, bf16 *__restrict__ dst, int D,
+                                                        int C, int pp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D * pp) return;
+    const int d = i / pp, k = i - d * pp;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += src[((size_t)d * C + c) * pp + k];
+    dst[i] = (bf16)s;
+}
+
+hipError_t launch_fold_cast_bf16(const float *src, bf16 *dst, int D, int C, int pp, hipStream_t s) {
+    const int n = D * pp;
+    fold_cast_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(src, dst, D, C, pp);
+    return hipGetLastError();
+}
+
+// prepare_tokens (:203-207), cls part: x[b][0][:] = cls_token + pos_embed[0].
+__global__ __launch_bounds__(256) void cls_rows_kernel(const float *__restrict__ cls, const float *__restrict__ pos,
+                                                       float *__restrict__ x, int batch, int n_tokens, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= batch * dim) return;
+    const int b = i / dim, c = i - b * dim;
+    x[(size_t)b * n_tokens * dim + c] = cls[c] + pos[c];
+}
+
+hipError_t launch_cls_rows(const float *cls, const float *pos, float *x, int batch, int n_tokens, int dim,
+                           hipStream_t s) {
+    const int n = batch * dim;
+    cls_rows_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(cls, pos, x, batch, n_tokens, dim);
+    return hipGetLastError();
+}

@@ -1,0 +1,180 @@
+"""Plumbing between torch-ROCm tensors and the C ABI (include/ocm_vit.h).
+
+torch is used for what the boundary needs and nothing else: device memory for inputs,
+outputs and workspace, the current HIP stream, and `torch.distributed`. All arithmetic
+of the hot path happens inside libocm_vit.so.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (OCM_LAST_ATTN_ONLY, OCM_OUT_ATTN, OCM_OUT_FEAT, OCM_OUT_QKV, OCM_OUT_ROWS,
+                   OCM_OUT_TOKENS, OcmVitConfig, OcmVitIO, check)
+
+
+def _require_hip(t, what):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(
+            f"{what} must live on a HIP device (got {getattr(t, 'device', type(t))}). This path runs only "
+            "through the gfx950 HIP extension; there is no CPU fallback.")
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    """Owns one ocm_vit_t handle (packed bf16/fp32 parameter copies in HBM) for one device."""
+
+    def __init__(self, *, patch_size, in_chans, embed_dim, depth, num_heads, mlp_hidden, ln_eps, qk_scale,
+                 device, precision=_lib.OCM_PREC_BF16):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Engine needs a HIP device (torch device type 'cuda' on ROCm); no CPU fallback.")
+        self.cfg = OcmVitConfig(patch_size, in_chans, embed_dim, depth, num_heads, mlp_hidden, ln_eps, qk_scale,
+                                precision, 0)
+        self.D, self.H, self.L, self.p = embed_dim, num_heads, depth, patch_size
+        self._h = C.c_void_p(0)
+        with torch.cuda.device(self.device):
+            check(self.lib.ocm_vit_create(C.byref(self.cfg), C.byref(self._h)))
+        self._ws = {}
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.ocm_vit_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters -------------------------------------------------------------------------
+    def set_param(self, name, tensor):
+        """Upload one state_dict entry (reference key name, reference layout)."""
+        t = tensor.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(self.device):
+            check(self.lib.ocm_vit_set_param(self._h, name.encode(), _p(t), t.numel(), _stream()))
+            # the source may be a temporary: keep it alive until the cast kernel has run
+            torch.cuda.current_stream().synchronize()
+
+    def n_tokens(self, tile_h, tile_w):
+        return (tile_h // self.p) * (tile_w // self.p) + 1
+
+    def workspace(self, batch, n):
+        key = (batch, n)
+        ws = self._ws.get(key)
+        if ws is None:
+            nbytes = self.lib.ocm_vit_workspace_bytes(self._h, batch, n)
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+            self._ws = {key: ws}  # keep only the latest shape resident
+        off = (-ws.data_ptr()) % 256
+        return ws.data_ptr() + off, ws.numel() - off
+
+    # ---- forward ----------------------------------------------------------------------------
+    def _io(self, image, strides, origins, batch, tile_h, tile_w, pos):
+        io = OcmVitIO()
+        io.image = image.data_ptr()
+        io.img_stride_b, io.img_stride_c, io.img_stride_y = strides
+        io.tile_origins = origins.data_ptr() if origins is not None else None
+        io.batch, io.tile_h, io.tile_w = batch, tile_h, tile_w
+        io.pos_embed = pos.data_ptr()
+        io.stream = torch.cuda.current_stream().cuda_stream
+        return io
+
+    def forward_tiles(self, image, strides, origins, batch, tile_h, tile_w, pos, *, flags, n_last=1,
+                      query_rows=None):
+        """One ocm_vit_forward. `image` is an fp32 HIP tensor holding the planes, `strides`
+        = (batch, channel, row) element strides, `origins` an int32 (B,2) HIP tensor or None.
+        Returns a dict with the requested outputs (fresh tensors)."""
+        _require_hip(image, "image")
+        _require_hip(pos, "pos_embed")
+        if image.dtype != torch.float32:
+            raise ValueError(f"image must be float32 (got {image.dtype})")
+        n = self.n_tokens(tile_h, tile_w)
+        if tuple(pos.shape) != (n, self.D) or pos.dtype != torch.float32 or not pos.is_contiguous():
+            raise AssertionError(f"pos_embed must be a contiguous float32 ({n},{self.D}) tensor, got {tuple(pos.shape)}")
+        B, D, H = batch, self.D, self.H
+        out = {}
+        with torch.cuda.device(self.device):
+            io = self._io(image, strides, origins, B, tile_h, tile_w, pos)
+            io.flags, io.n_last = flags, n_last
+            kw = dict(dtype=torch.float32, device=self.device)
+            if flags & OCM_OUT_FEAT:
+                out["feat"] = torch.empty((n_last, B, n, D), **kw)
+                io.out_feat = out["feat"].data_ptr()
+            if flags & OCM_OUT_ATTN:
+                out["attn"] = torch.empty((n_last, B, H, n, n), **kw)
+                io.out_attn = out["attn"].data_ptr()
+            if flags & OCM_OUT_QKV:
+                out["qkv"] = torch.empty((n_last, 3, B, H, n, 64), **kw)
+                io.out_qkv = out["qkv"].data_ptr()
+            if flags & OCM_OUT_TOKENS:
+                out["tokens"] = torch.empty((B, n, D), **kw)
+                io.out_tokens = out["tokens"].data_ptr()
+            if flags & OCM_OUT_ROWS:
+                if query_rows is None:
+                    query_rows = torch.zeros(1, dtype=torch.int32, device=self.device)
+                _require_hip(query_rows, "query_rows")
+                query_rows = query_rows.to(torch.int32).contiguous()
+                out["rows"] = torch.empty((B, H, query_rows.numel(), n - 1), **kw)
+                io.query_rows, io.n_rows = query_rows.data_ptr(), query_rows.numel()
+                io.out_rows = out["rows"].data_ptr()
+            io.workspace, io.workspace_bytes = self.workspace(B, n)
+            check(self.lib.ocm_vit_forward(self._h, C.byref(io)))
+        return out
+
+    def forward(self, x, pos, **kw):
+        """x: (B, C, Hpx, Wpx) fp32 HIP tensor (any strides with unit x stride)."""
+        _require_hip(x, "input")
+        if x.dim() != 4:
+            raise ValueError(f"expected a (B,C,H,W) tensor, got {tuple(x.shape)}")
+        if x.stride(3) != 1:
+            x = x.contiguous()
+        B, Cc, Hpx, Wpx = x.shape
+        if Cc != self.cfg.in_chans:
+            raise ValueError(f"input has {Cc} channels, engine was built for {self.cfg.in_chans}")
+        return self.forward_tiles(x, (x.stride(0), x.stride(1), x.stride(2)), None, B, Hpx, Wpx, pos, **kw)
+
+    def prepare_tokens(self, x, pos):
+        _require_hip(x, "input")
+        if x.stride(3) != 1:
+            x = x.contiguous()
+        B, Cc, Hpx, Wpx = x.shape
+        n = self.n_tokens(Hpx, Wpx)
+        with torch.cuda.device(self.device):
+            io = self._io(x, (x.stride(0), x.stride(1), x.stride(2)), None, B, Hpx, Wpx, pos)
+            out = torch.empty((B, n, self.D), dtype=torch.float32, device=self.device)
+            check(self.lib.ocm_vit_prepare_tokens(self._h, C.byref(io), _p(out)))
+        return out
+
+    def block_forward(self, index, x, *, want_attn=False, want_qkv=False, attn_only=False):
+        """Block.forward on x (B,N,D) fp32; returns (x_out | None, attn | None, qkv | None)."""
+        _require_hip(x, "x")
+        B, n, D = x.shape
+        xo = x.detach().to(torch.float32).contiguous().clone()
+        flags = (OCM_OUT_ATTN if want_attn else 0) | (OCM_OUT_QKV if want_qkv else 0) | \
+                (OCM_LAST_ATTN_ONLY if attn_only else 0)
+        kw = dict(dtype=torch.float32, device=self.device)
+        attn = torch.empty((B, self.H, n, n), **kw) if want_attn else None
+        qkv = torch.empty((3, B, self.H, n, 64), **kw) if want_qkv else None
+        with torch.cuda.device(self.device):
+            ws, wsb = self.workspace(B, n)
+            check(self.lib.ocm_vit_block_forward(self._h, index, _p(xo), B, n, flags, _p(attn), _p(qkv), ws, wsb,
+                                                 _stream()))
+        return (None if attn_only else xo), attn, qkv
+
+    def final_norm(self, x):
+        _require_hip(x, "x")
+        xc = x.detach().to(torch.float32).contiguous()
+        y = torch.empty_like(xc)
+        with torch.cuda.device(self.device):
+            check(self.lib.ocm_vit_final_norm(self._h, _p(xc), _p(y), xc.numel() // self.D, _stream()))
+        return y
