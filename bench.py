@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py — OCM tiles/s of the ViT attention-map hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): ViT-S/16, batch 64 of 224x224 synthetic OCM tiles per GPU,
+bf16 MFMA operands / fp32 accumulate, attention-map extraction = `get_last_selfattention`
+(full (B,H,N,N) fp32 probabilities of the last block) + the CLS-row maps callers consume.
+A step = one such forward over one resident batch on every rank (weak scaling: the tiles of a
+sweep are independent) followed by the all-gather of the per-tile CLS-row maps
+(RCCL, overlapped with the next step's compute). Inputs and weights are in HBM before the timed
+region. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+
+
+def flops_per_tile(D, L, p, S, in_chans=3):
+    """Algorithmic MFMA FLOPs (1 MAC = 2), SURVEY §8-d: F_map = F_pe + (L-1) F_block + 6ND^2 + 2N^2D."""
+    P = (S // p) ** 2
+    N = P + 1
+    f_block = 24 * N * D * D + 4 * N * N * D
+    f_pe = 2 * P * in_chans * p * p * D
+    return f_pe + (L - 1) * f_block + 6 * N * D * D + 2 * N * N * D, N
+
+
+def class_flops(D, M, N, B, p, in_chans):
+    """Algorithmic FLOPs of ONE launch of each kernel class at batch B (per-unit figure x units)."""
+    T, P = B * N, N - 1
+    return {
+        "patch_embed": 2.0 * B * P * in_chans * p * p * D,
+        "qkv_gemm": 2.0 * T * D * 3 * D,
+        "attention": 4.0 * B * N * N * D,  # QK^T + PV over all heads
+        "proj_gemm": 2.0 * T * D * D,
+        "fc1_gemm": 2.0 * T * D * M,
+        "fc2_gemm": 2.0 * T * M * D,
+    }
+
+
+def cpu_baseline(arch_dims, patch, size, batch, seconds_budget=20.0):
+    """The oracle (CPU restatement of the reference, fp32 torch-CPU ops) timed on this host."""
+    from oracle import vit_oracle as O  # CPU baseline leg: allowed importer of oracle/
+    from vit_ocm_wmsegmentation_amd import synth
+    D, L, H = arch_dims
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = synth.synth_state_dict(D, L, patch, seed=0, variant="init")
+    cfg = O.make_cfg(sd, patch, H)
+    x = synth.synth_tiles(batch, size)
+    O.get_last_selfattention(sd, cfg, x)  # warm-up
+    t0 = time.perf_counter()
+    iters = 0
+    while iters < 5 and (iters < 2 or time.perf_counter() - t0 < seconds_budget):
+        O.get_last_selfattention(sd, cfg, x)
+        iters += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * iters / dt, 2), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} batches of {batch} tiles ({size}x{size}, get_last_selfattention, fp32 torch-CPU "
+                      f"oracle, {cores} threads) after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--arch", default="vit_small")
+    ap.add_argument("--patch", type=int, default=16)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-class table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import vit_ocm_wmsegmentation_amd.dino.vision_transformer as vits
+    from vit_ocm_wmsegmentation_amd import _lib, synth
+    lib = _lib.load()
+
+    D, L, H = synth.ARCHS[args.arch]
+    B, S, p = args.batch, args.size, args.patch
+    model = vits.__dict__[args.arch](patch_size=p, num_classes=0)
+    model.load_state_dict(synth.synth_arch_state_dict(args.arch, p, seed=0, variant="init"))
+    for q in model.parameters():
+        q.requires_grad = False
+    model.eval().to(dev)
+    x = synth.synth_tiles(B, S, seed=1234 + rank).to(dev)  # resident in HBM before timing
+    fmap, N = flops_per_tile(D, L, p, S)
+
+    flags = _lib.OCM_OUT_ATTN | _lib.OCM_OUT_ROWS | _lib.OCM_LAST_ATTN_ONLY
+    gathered = torch.empty((world * B, H, 1, N - 1), dtype=torch.float32, device=dev) if world > 1 else None
+    pending = None
+
+    def step():
+        nonlocal pending
+        out = model._run(x, flags=flags)  # full (B,H,N,N) attention + CLS rows (B,H,1,N-1)
+        if world > 1:
+            if pending is not None:
+                pending.wait()
+            pending = dist.all_gather_into_tensor(gathered, out["rows"], async_op=True)
+        return out
+
+    def sync():
+        nonlocal pending
+        if pending is not None:
+            pending.wait()
+            pending = None
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+
+    # dominant kernel class: measured live with HIP events on the launch stream, inside the timed region
+    dom = "fc1_gemm"
+    dom_idx = _lib.KERNEL_CLASSES.index(dom)
+    _lib.check(lib.ocm_prof_begin(1 << dom_idx, args.steps * L + 8))
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    sync()
+    dt = time.perf_counter() - t0
+    ms = (C.c_double * len(_lib.KERNEL_CLASSES))()
+    cnt = (C.c_int64 * len(_lib.KERNEL_CLASSES))()
+    _lib.check(lib.ocm_prof_end(ms, cnt))
+    dom_ms, dom_n = ms[dom_idx], cnt[dom_idx]
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # per-class breakdown (separate, untimed pass: events around every launch)
+    breakdown = None
+    if rank == 0:
+        reps = 5
+        _lib.check(lib.ocm_prof_begin(0xFFFFFFFF, reps * (8 * L + 8)))
+        for _ in range(reps):
+            model._run(x, flags=flags)
+        torch.cuda.synchronize()
+        _lib.check(lib.ocm_prof_end(ms, cnt))
+        cf = class_flops(D, int(D * 4), N, B, p, 3)
+        breakdown = {}
+        for i, name in enumerate(_lib.KERNEL_CLASSES):
+            if cnt[i]:
+                avg_us = ms[i] / cnt[i] * 1e3
+                breakdown[name] = {"launches_per_fwd": cnt[i] // reps, "avg_us": round(avg_us, 2),
+                                   "us_per_fwd": round(ms[i] / reps * 1e3, 1)}
+                if name in cf:
+                    breakdown[name]["tflops"] = round(cf[name] / (avg_us * 1e-6) / 1e12, 1)
+        if args.breakdown:
+            tot = sum(v["us_per_fwd"] for v in breakdown.values())
+            print(f"per-class device time per forward (sum {tot:.0f} us):", file=sys.stderr)
+            for k, v in breakdown.items():
+                print(f"  {k:12s} {v}", file=sys.stderr)
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # parity of what was just timed: attention-map L_inf vs the CPU oracle on the first tiles
+    from oracle import vit_oracle as O  # checker
+    sd = synth.synth_arch_state_dict(args.arch, p, seed=0, variant="init")
+    cfg = O.make_cfg(sd, p, H)
+    nchk = min(2, B)
+    ref = O.get_last_selfattention(sd, cfg, x[:nchk].cpu())
+    linf = float((out["attn"][0][:nchk].cpu() - ref).abs().max())
+
+    tiles = B * world * args.steps
+    value = tiles / dt
+    cf = class_flops(D, int(D * 4), N, B, p, 3)
+    dom_avg_s = dom_ms / max(dom_n, 1) * 1e-3
+    achieved = cf[dom] / dom_avg_s / 1e12 if dom_n else None
+    line = {
+        "metric": "OCM tiles/s (224x224, ViT-S/16 attention-map inference)" if (args.arch, p, S) == ("vit_small", 16, 224)
+        else f"OCM tiles/s ({S}x{S}, {args.arch}/{p} attention-map inference)",
+        "value": round(value, 1),
+        "unit": "tiles/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"{args.arch} patch {p}, {B} tiles/GPU of {S}x{S} (RGB-replicated grayscale), "
+                               f"get_last_selfattention -> (B,{H},{N},{N}) fp32 + CLS-row maps; random-init weights",
+                   "tiles_per_gpu": B, "tokens": N, "parallelism": f"tile-shard x{world}" + (" + all-gather" if world > 1 else "")},
+        "attn_linf_vs_cpu_oracle": linf,
+        "path_tflops": round(value * fmap / 1e12, 2),
+        "path_frac_of_bf16_peak": round(value * fmap / 1e12 / (PEAK_BF16_DENSE_TFLOPS * world), 4),
+        "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2) if achieved else None,
+                     "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4) if achieved else None,
+                     "traffic": None, "launches": int(dom_n), "avg_launch_us": round(dom_avg_s * 1e6, 2),
+                     "flop_per_launch": cf[dom]},
+        "kernel_breakdown": breakdown,
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline((D, L, H), p, S, B)
+    print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -207,6 +207,25 @@ int ocm_op_attention_map(const float *attn, float *maps, int32_t b, int32_t head
                          int32_t n_tokens, int32_t query, int32_t hf, int32_t wf, int32_t p,
                          void *stream);
 
+/* ---- in-library kernel timing (diagnostic; process-wide, single host thread) --------------------
+ * While enabled, every launch of a kernel class selected in `class_mask` is bracketed by two
+ * hipEvents recorded on the launch stream (no host synchronisation). ocm_prof_end() waits for the
+ * recorded events, returns per-class launch counts and summed device milliseconds, and disables
+ * profiling. bench.py uses it for the live per-kernel duration behind its `roofline` object. */
+enum {
+    OCM_K_PATCH = 0, /* patch-embedding gather + GEMM                 */
+    OCM_K_LN = 1,    /* LayerNorm                                      */
+    OCM_K_QKV = 2,   /* qkv projection GEMM                            */
+    OCM_K_ATTN = 3,  /* flash attention (scores + softmax + P.V)       */
+    OCM_K_PROBS = 4, /* attention-probability materialisation / rows   */
+    OCM_K_PROJ = 5,  /* attn.proj GEMM + residual                      */
+    OCM_K_FC1 = 6,   /* mlp.fc1 GEMM + GELU                            */
+    OCM_K_FC2 = 7,   /* mlp.fc2 GEMM + residual                        */
+    OCM_K_COUNT = 8
+};
+int ocm_prof_begin(uint32_t class_mask, int32_t max_launches);
+int ocm_prof_end(double *ms_per_class /*[OCM_K_COUNT]*/, int64_t *launches_per_class /*[OCM_K_COUNT]*/);
+
 /* ---- sliding-window index math (host, integer; sw_processing.py:151-163) ---- */
 /* Number of windows per axis: len(range(0, size - 2*stride, stride)). */
 int32_t ocm_sw_count(int32_t size, int32_t stride);

@@ -1,0 +1,187 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+CPU restatement (fp32, plain torch-CPU functional ops, the reference's own op order) of the one hot
+path this repository accelerates: the ViT forward of
+    /root/reference/Self-supervised_segmentation/dino/vision_transformer.py
+plus the few lines of its callers that define the output contract. Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import this file — as the
+checker or the timed CPU baseline, never as something the product calls. The product
+(`vit-ocm-wmsegmentation_amd/`) imports nothing from here and has no CPU fallback.
+
+Parity is PINNED: `oracle/make_golden.py` imports the real reference module in the build container,
+loads the same synthetic state_dict into it, asserts this restatement agrees to <= 1e-6 on every
+output and writes `tests/golden/*.npz`; `tests/test_oracle_golden.py` re-checks the restatement
+against those fixtures wherever the tests run (the reference itself never travels).
+
+Everything operates on a flat `sd` = {state_dict key: fp32 tensor} (keys of SURVEY §8-b) and a
+`cfg` dict(patch_size, num_heads, depth, eps, scale). Each function cites the reference lines
+it restates (paths relative to Self-supervised_segmentation/).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def make_cfg(sd, patch_size, num_heads, eps=1e-6, qk_scale=None):
+    depth = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    dim = sd["cls_token"].shape[-1]
+    return dict(patch_size=patch_size, num_heads=num_heads, depth=depth, eps=eps,
+                scale=qk_scale or (dim // num_heads) ** -0.5)
+
+
+def patch_embed(sd, x, p):
+    """dino/vision_transformer.py:129-132 — Conv2d(k=p, s=p) -> flatten(2) -> transpose(1, 2)."""
+    y = F.conv2d(x, sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"], stride=p)
+    return y.flatten(2).transpose(1, 2)
+
+
+def interpolate_pos_encoding(sd, npatch, w, h, p):
+    """dino/vision_transformer.py:176-196."""
+    pos = sd["pos_embed"]
+    n0 = pos.shape[1] - 1
+    if npatch == n0 and w == h:
+        return pos
+    cls_pos, patch_pos = pos[:, 0], pos[:, 1:]
+    dim = pos.shape[-1]
+    w0, h0 = w // p + 0.1, h // p + 0.1
+    side = int(math.sqrt(n0))
+    patch_pos = F.interpolate(patch_pos.reshape(1, side, side, dim).permute(0, 3, 1, 2),
+                              scale_factor=(w0 / math.sqrt(n0), h0 / math.sqrt(n0)), mode="bicubic")
+    assert int(w0) == patch_pos.shape[-2] and int(h0) == patch_pos.shape[-1]
+    patch_pos = patch_pos.permute(0, 2, 3, 1).view(1, -1, dim)
+    return torch.cat((cls_pos.unsqueeze(0), patch_pos), dim=1)
+
+
+def prepare_tokens(sd, cfg, x):
+    """dino/vision_transformer.py:198-209 (pos_drop is p=0)."""
+    B, _, w, h = x.shape
+    t = patch_embed(sd, x, cfg["patch_size"])
+    t = torch.cat((sd["cls_token"].expand(B, -1, -1), t), dim=1)
+    return t + interpolate_pos_encoding(sd, t.shape[1] - 1, w, h, cfg["patch_size"])
+
+
+def layer_norm(sd, prefix, x, eps):
+    """nn.LayerNorm(D, eps=1e-6) — :98,102,158 with eps from :262-278."""
+    return F.layer_norm(x, (x.shape[-1],), sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
+
+
+def attention(sd, cfg, i, x):
+    """Attention.forward, dino/vision_transformer.py:78-90 -> (x, attn, qkv)."""
+    B, N, Cd = x.shape
+    H = cfg["num_heads"]
+    pre = f"blocks.{i}.attn."
+    qkv = F.linear(x, sd[pre + "qkv.weight"], sd.get(pre + "qkv.bias"))
+    qkv = qkv.reshape(B, N, 3, H, Cd // H).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)) * cfg["scale"]
+    attn = attn.softmax(dim=-1)
+    y = (attn @ v).transpose(1, 2).reshape(B, N, Cd)
+    y = F.linear(y, sd[pre + "proj.weight"], sd[pre + "proj.bias"])
+    return y, attn, qkv
+
+
+def mlp(sd, i, x):
+    """Mlp.forward, dino/vision_transformer.py:57-63 (exact-erf GELU, dropout p=0)."""
+    pre = f"blocks.{i}.mlp."
+    return F.linear(F.gelu(F.linear(x, sd[pre + "fc1.weight"], sd[pre + "fc1.bias"])), sd[pre + "fc2.weight"],
+                    sd[pre + "fc2.bias"])
+
+
+def block(sd, cfg, i, x, return_attention=False):
+    """Block.forward, dino/vision_transformer.py:106-114."""
+    y, attn, qkv = attention(sd, cfg, i, layer_norm(sd, f"blocks.{i}.norm1", x, cfg["eps"]))
+    if return_attention:
+        return attn
+    x = x + y
+    x = x + mlp(sd, i, layer_norm(sd, f"blocks.{i}.norm2", x, cfg["eps"]))
+    return x, attn, qkv
+
+
+@torch.no_grad()
+def get_intermediate_feat(sd, cfg, x, n=1):
+    """dino/vision_transformer.py:225-237 -> (feat, attns, qkvs) lists of length n."""
+    x = prepare_tokens(sd, cfg, x)
+    feat, attns, qkvs = [], [], []
+    for i in range(cfg["depth"]):
+        x, attn, qkv = block(sd, cfg, i, x)
+        if cfg["depth"] - i <= n:
+            feat.append(layer_norm(sd, "norm", x, cfg["eps"]))
+            qkvs.append(qkv)
+            attns.append(attn)
+    return feat, attns, qkvs
+
+
+@torch.no_grad()
+def get_last_selfattention(sd, cfg, x):
+    """dino/vision_transformer.py:239-246."""
+    x = prepare_tokens(sd, cfg, x)
+    for i in range(cfg["depth"]):
+        if i < cfg["depth"] - 1:
+            x = block(sd, cfg, i, x)[0]
+        else:
+            return block(sd, cfg, i, x, return_attention=True)
+
+
+@torch.no_grad()
+def forward_feats(sd, cfg, x):
+    """dino/vision_transformer.py:218-223 (forward :211-216 is [:, 0] of this)."""
+    x = prepare_tokens(sd, cfg, x)
+    for i in range(cfg["depth"]):
+        x = block(sd, cfg, i, x)[0]
+    return layer_norm(sd, "norm", x, cfg["eps"])
+
+
+@torch.no_grad()
+def get_intermediate_layers(sd, cfg, x, n=1):
+    """dino/vision_transformer.py:248-256."""
+    x = prepare_tokens(sd, cfg, x)
+    out = []
+    for i in range(cfg["depth"]):
+        x = block(sd, cfg, i, x)[0]
+        if cfg["depth"] - i <= n:
+            out.append(layer_norm(sd, "norm", x, cfg["eps"]))
+    return out
+
+
+def compute_attention(attentions, query, w_featmap, h_featmap, patch_size):
+    """utils.py:229-235 (the module itself needs cv2/skimage, absent here: restated from its text)."""
+    a = attentions[0]
+    nh = a.shape[1]
+    a = a[0, :, query, 1:].reshape(nh, -1)
+    a = a.reshape(nh, w_featmap, h_featmap)
+    a = F.interpolate(a.unsqueeze(0), scale_factor=patch_size, mode="nearest")[0].cpu().numpy()
+    return a, nh
+
+
+def region_query_index(py, px, patch_size, w_featmap):
+    """analyse_attention.py:192-193."""
+    return int(py // patch_size * w_featmap + px // patch_size)
+
+
+def sliding_window_origins(height, width, stride):
+    """sw_processing.py:151-163: `for y in range(0, height - stride*2, stride): for x in range(0,
+    width - stride*2, stride)`, row-major; returns [(y, x), ...]. (The reference unpacks
+    `height, width = image.size`, PIL's (W, H); it only runs on square images.)"""
+    return [(y, x) for y in range(0, height - stride * 2, stride) for x in range(0, width - stride * 2, stride)]
+
+
+def sliding_window_crops(image_chw, stride, window):
+    """The crops of sw_processing.py:157-160 as a (T, C, window, window) tensor (PIL crop ==
+    array slice for in-bounds boxes)."""
+    _, H, W = image_chw.shape
+    return torch.stack([image_chw[:, y:y + window, x:x + window] for y, x in sliding_window_origins(H, W, stride)])
+
+
+def tile_head_mean_maps(sd, cfg, tiles, patch_size):
+    """The per-tile body of the serial loop sw_processing.py:235-245 at B=1 per call:
+    get_intermediate_feat -> compute_attention(query 0) -> mean over heads. Returns
+    (T, window, window) float32 numpy."""
+    out = []
+    for j in range(tiles.shape[0]):
+        crop = tiles[j:j + 1]
+        _, attns, _ = get_intermediate_feat(sd, cfg, crop, n=1)
+        a, _ = compute_attention(attns, 0, crop.shape[-2] // patch_size, crop.shape[-1] // patch_size, patch_size)
+        out.append(np.mean(a, axis=0))
+    return np.stack(out)

@@ -1,0 +1,23 @@
+"""The golden-fixture cases: shared by oracle/make_golden.py (which writes tests/golden/<name>.npz from
+the real reference) and by the tests (which regenerate weights/inputs from the same seeds).
+  arch | (dim, depth, heads): model;  patch, img_size: constructor;  variant, seed: synth.synth_state_dict;
+  inputs: [(batch, height, width, tile_seed)];  n: last-n blocks returned;  full: store complete tensors."""
+CASES = {
+    # name: dict(ctor=..., heads, patch, img_size, variant, seed, inputs=[(B, H, W, seed)], n)
+    "tiny_p8": dict(dim=128, depth=2, heads=2, patch=8, img_size=32, variant="full", seed=1,
+                    inputs=[(2, 32, 32, 11), (1, 48, 32, 12)], n=2, full=True),
+    "vits16_full": dict(arch="vit_small", patch=16, img_size=224, variant="full", seed=0,
+                        inputs=[(2, 224, 224, 1234)], n=1),
+    "vits16_sharp": dict(arch="vit_small", patch=16, img_size=224, variant="sharp", seed=0,
+                         inputs=[(2, 224, 224, 1234)], n=1),
+    "vits16_peaked": dict(arch="vit_small", patch=16, img_size=224, variant="peaked", seed=0,
+                          inputs=[(2, 224, 224, 1234)], n=1),
+    "vits16_init": dict(arch="vit_small", patch=16, img_size=224, variant="init", seed=0,
+                        inputs=[(1, 224, 224, 1234)], n=1),
+    "vitt16_full": dict(arch="vit_tiny", patch=16, img_size=224, variant="full", seed=3,
+                        inputs=[(1, 224, 224, 77)], n=1),
+    "vits8_384_sharp": dict(arch="vit_small", patch=8, img_size=224, variant="sharp", seed=0,
+                            inputs=[(1, 384, 384, 4321)], n=1),
+    "vitb16_384_full": dict(arch="vit_base", patch=16, img_size=224, variant="full", seed=0,
+                            inputs=[(1, 384, 384, 99)], n=1),
+}

@@ -1,0 +1,68 @@
+"""The oracle (oracle/vit_oracle.py, the CPU restatement) against the golden vectors that
+oracle/make_golden.py captured from the REAL reference module. Runs anywhere (CPU only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vit_oracle as O
+from tests.helpers import CASES, case_dims, case_inputs, case_state_dict, load_golden
+
+# fp32 CPU arithmetic re-run on possibly different host cores / thread counts: summation order of
+# MKL / oneDNN kernels may differ, so allow a few ulps of the O(1) activations.
+TOL = 2e-5
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference_golden(name):
+    case, gold = CASES[name], load_golden(name)
+    assert float(gold["oracle_vs_reference_maxabs"]) <= 1e-6  # pinned when the fixture was made
+    sd = case_state_dict(case)
+    cfg = O.make_cfg(sd, case["patch"], case_dims(case)[2])
+    for idx, x in enumerate(case_inputs(case)):
+        pfx = f"in{idx}_"
+        n = case["n"]
+        feat, attns, qkvs = O.get_intermediate_feat(sd, cfg, x, n)
+        a = attns[-1]
+        np.testing.assert_allclose(a[:, :, 0, 1:].numpy(), gold[pfx + "cls_rows"], rtol=0, atol=TOL)
+        np.testing.assert_allclose(a[:, :, a.shape[-1] // 2, :].numpy(), gold[pfx + "mid_rows"], rtol=0, atol=TOL)
+        assert np.array_equal(a[:, :, 0, 1:].mean(1).argmax(-1).numpy(), gold[pfx + "argmax"])  # indices: exact
+        np.testing.assert_allclose(feat[-1][:, :4, :16].numpy(), gold[pfx + "feat_head"], rtol=0, atol=10 * TOL)
+        assert abs(float(feat[-1].double().abs().sum()) / float(gold[pfx + "feat_abssum"]) - 1) < 1e-5
+        np.testing.assert_allclose(qkvs[-1][:, :, :, :3, :8].numpy(), gold[pfx + "qkv_head"], rtol=0, atol=10 * TOL)
+        tokens = O.prepare_tokens(sd, cfg, x)
+        np.testing.assert_allclose(tokens[:, :3, :16].numpy(), gold[pfx + "tokens_head"], rtol=0, atol=TOL)
+        assert abs(float(tokens.double().abs().sum()) / float(gold[pfx + "tokens_abssum"]) - 1) < 1e-6
+        if name in ("tiny_p8", "vits16_init"):  # the cheap cases also pin the other entry points
+            assert torch.equal(O.get_last_selfattention(sd, cfg, x), a)
+            np.testing.assert_allclose(O.forward_feats(sd, cfg, x)[:, 0, :32].numpy(), gold[pfx + "cls_out"],
+                                       rtol=0, atol=10 * TOL)
+        if case.get("full"):
+            for j in range(n):
+                np.testing.assert_allclose(feat[j].numpy(), gold[pfx + f"feat{j}"], rtol=0, atol=10 * TOL)
+                np.testing.assert_allclose(attns[j].numpy(), gold[pfx + f"attn{j}"], rtol=0, atol=TOL)
+                np.testing.assert_allclose(qkvs[j].numpy(), gold[pfx + f"qkv{j}"], rtol=0, atol=10 * TOL)
+
+
+def test_compute_attention_contract():
+    """utils.py:229-235: batch 0, one query row, CLS column dropped, (w,h) row-major, nearest x p."""
+    B, H, wf, hf, p = 2, 3, 4, 5, 8
+    N = wf * hf + 1
+    attn = torch.arange(B * H * N * N, dtype=torch.float32).reshape(B, H, N, N)
+    maps, nh = O.compute_attention([attn], 7, wf, hf, p)
+    assert nh == H and maps.shape == (H, wf * p, hf * p)
+    for head in range(H):
+        for ty in range(wf):
+            for tx in range(hf):
+                blockv = maps[head, ty * p:(ty + 1) * p, tx * p:(tx + 1) * p]
+                assert (blockv == attn[0, head, 7, 1 + ty * hf + tx].item()).all()
+    assert O.region_query_index(37, 90, 16, 14) == 37 // 16 * 14 + 90 // 16
+
+
+def test_sliding_window_origins_restatement():
+    """sw_processing.py:151-163 on the sizes the reference / BASELINE use."""
+    o = O.sliding_window_origins(1152, 1152, 128)
+    assert len(o) == 49 and o[0] == (0, 0) and o[1] == (0, 128) and o[7] == (128, 0) and o[-1] == (768, 768)
+    o = O.sliding_window_origins(4096, 4096, 128)
+    assert len(o) == 900 and o[-1] == (3712, 3712) and o[-1][0] + 384 == 4096
+    assert O.sliding_window_origins(256, 256, 128) == []  # size - 2*stride <= 0: no window
+    assert O.sliding_window_origins(384, 384, 128) == [(0, 0)]

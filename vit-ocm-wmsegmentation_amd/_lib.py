@@ -21,6 +21,9 @@ OCM_OUT_TOKENS = 1 << 3
 OCM_OUT_ROWS = 1 << 4
 OCM_LAST_ATTN_ONLY = 1 << 5
 
+KERNEL_CLASSES = ("patch_embed", "layernorm", "qkv_gemm", "attention", "attn_probs", "proj_gemm", "fc1_gemm",
+                  "fc2_gemm")
+
 OCM_EPI_BIAS_F32 = 0
 OCM_EPI_BIAS_RESID_F32 = 1
 OCM_EPI_BIAS_GELU_BF16 = 2
@@ -92,6 +95,8 @@ SIGNATURES = {
     "ocm_op_attention_probs": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "ocm_op_attention_rows": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp]),
     "ocm_op_attention_map": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "ocm_prof_begin": (C.c_int, [C.c_uint32, _i32]),
+    "ocm_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_i64)]),
     "ocm_sw_count": (_i32, [_i32, _i32]),
     "ocm_sw_origins": (_i32, [_i32, _i32, _i32, C.POINTER(_i32), _i32]),
     "ocm_sw_shard": (_i32, [_i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32)]),

@@ -29,6 +29,72 @@ static int fail(int code, const char *fmt, ...) {
                                           __FILE__, __LINE__);                                    \
     } while (0)
 
+// ------------------------------------------------------------------------------------------
+// kernel-class timing with hipEvents (diagnostic)
+// ------------------------------------------------------------------------------------------
+struct Prof {
+    bool on = false;
+    uint32_t mask = 0;
+    std::vector<hipEvent_t> ev;  // pairs
+    std::vector<int> cls;
+    size_t used = 0;             // pairs used
+};
+static Prof g_prof;
+
+struct ProfScope {
+    hipStream_t s;
+    int idx = -1;
+    ProfScope(int kclass, hipStream_t stream) : s(stream) {
+        if (g_prof.on && (g_prof.mask >> kclass & 1) && g_prof.used * 2 + 1 < g_prof.ev.size()) {
+            idx = (int)g_prof.used++;
+            g_prof.cls[idx] = kclass;
+            (void)hipEventRecord(g_prof.ev[2 * idx], s);
+        }
+    }
+    ~ProfScope() {
+        if (idx >= 0) (void)hipEventRecord(g_prof.ev[2 * idx + 1], s);
+    }
+};
+#define PROF(kclass, stream) ProfScope prof_scope_##__LINE__(kclass, stream)
+
+extern "C" int ocm_prof_begin(uint32_t class_mask, int32_t max_launches) {
+    if (g_prof.on) return fail(OCM_ESTATE, "profiling already active");
+    if (max_launches <= 0) return fail(OCM_EINVAL, "max_launches must be positive");
+    g_prof.ev.resize((size_t)max_launches * 2);
+    g_prof.cls.assign(max_launches, 0);
+    for (auto &e : g_prof.ev) HIP_TRY(hipEventCreate(&e));
+    g_prof.used = 0;
+    g_prof.mask = class_mask;
+    g_prof.on = true;
+    return OCM_OK;
+}
+
+extern "C" int ocm_prof_end(double *ms_per_class, int64_t *launches_per_class) {
+    if (!g_prof.on) return fail(OCM_ESTATE, "profiling is not active");
+    g_prof.on = false;
+    for (int c = 0; c < OCM_K_COUNT; ++c) {
+        if (ms_per_class) ms_per_class[c] = 0.0;
+        if (launches_per_class) launches_per_class[c] = 0;
+    }
+    int rc = OCM_OK;
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(g_prof.ev[2 * i + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+        if (e != hipSuccess) {
+            rc = fail(OCM_EHIP, "event timing failed: %s", hipGetErrorString(e));
+            break;
+        }
+        if (ms_per_class) ms_per_class[g_prof.cls[i]] += ms;
+        if (launches_per_class) launches_per_class[g_prof.cls[i]] += 1;
+    }
+    for (auto &e : g_prof.ev) (void)hipEventDestroy(e);
+    g_prof.ev.clear();
+    g_prof.cls.clear();
+    g_prof.used = 0;
+    return rc;
+}
+
 extern "C" int ocm_abi_version(void) { return OCM_ABI_VERSION; }
 extern "C" const char *ocm_last_error(void) { return g_err.c_str(); }
 extern "C" int32_t ocm_n_pad(int32_t n_tokens) { return ocm_round_up(n_tokens, 8); }
@@ -225,24 +291,24 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     const int D = h->D, H = h->H, T = batch * n, np = ocm_n_pad(n);
     const float eps = h->cfg.ln_eps, scale = h->cfg.qk_scale;
     // y = attn(norm1(x))
-    HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, true, T, D, eps, s));
-    HIP_TRY(launch_qkv(w.xn, h->ptr<bf16>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, w.vt, out_qkv, batch, n, np, H, s));
-    if (out_rows) HIP_TRY(launch_attention_rows(w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s));
+    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, true, T, D, eps, s)); }
+    { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(w.xn, h->ptr<bf16>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, w.vt, out_qkv, batch, n, np, H, s)); }
+    if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s)); }
     if (attn_only) {
         if (out_attn) {
-            HIP_TRY(launch_attention(w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s));
-            HIP_TRY(launch_attention_probs(w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s));
+            { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s)); }
+            { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
         }
         return OCM_OK;
     }
-    HIP_TRY(launch_attention(w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s));
-    if (out_attn) HIP_TRY(launch_attention_probs(w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s));
+    { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s)); }
+    if (out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
     // x = x + proj(ctx)
-    HIP_TRY(launch_linear(w.ctx, h->ptr<bf16>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s));
+    { PROF(OCM_K_PROJ, s); HIP_TRY(launch_linear(w.ctx, h->ptr<bf16>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s)); }
     // x = x + fc2(gelu(fc1(norm2(x))))
-    HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln2_g), h->ptr<float>(bp.ln2_b), w.xn, true, T, D, eps, s));
-    HIP_TRY(launch_linear(w.xn, h->ptr<bf16>(bp.fc1_w), h->ptr<float>(bp.fc1_b), nullptr, w.hid, T, h->M, D, OCM_EPI_BIAS_GELU_BF16, s));
-    HIP_TRY(launch_linear(w.hid, h->ptr<bf16>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s));
+    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln2_g), h->ptr<float>(bp.ln2_b), w.xn, true, T, D, eps, s)); }
+    { PROF(OCM_K_FC1, s); HIP_TRY(launch_linear(w.xn, h->ptr<bf16>(bp.fc1_w), h->ptr<float>(bp.fc1_b), nullptr, w.hid, T, h->M, D, OCM_EPI_BIAS_GELU_BF16, s)); }
+    { PROF(OCM_K_FC2, s); HIP_TRY(launch_linear(w.hid, h->ptr<bf16>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s)); }
     return OCM_OK;
 }
 
@@ -263,6 +329,7 @@ static int run_prepare(const ocm_vit *h, const ocm_vit_io *io, float *x, int n, 
     PatchArgs pa{io->image, io->img_stride_b, io->img_stride_c, io->img_stride_y, io->tile_origins,
                  io->batch, io->tile_h / h->p, io->tile_w / h->p, h->p, h->C};
     HIP_TRY(launch_cls_rows(h->ptr<float>(h->cls), io->pos_embed, x, io->batch, n, h->D, s));
+    PROF(OCM_K_PATCH, s);
     HIP_TRY(launch_patch_embed(pa, h->ptr<bf16>(h->pe_w), h->ptr<float>(h->pe_b), io->pos_embed, x, h->D, s));
     return OCM_OK;
 }
@@ -333,9 +400,11 @@ extern "C" int ocm_vit_forward(ocm_vit_t *h, const ocm_vit_io *io) {
         float *orow = (last && (fl & OCM_OUT_ROWS)) ? io->out_rows : nullptr;
         if ((rc = run_block(h, i, w, w.x, B, n, attn_only && last, oa, oq, io->query_rows, io->n_rows, orow, s)))
             return rc;
-        if (ret && (fl & OCM_OUT_FEAT))
+        if (ret && (fl & OCM_OUT_FEAT)) {
+            PROF(OCM_K_LN, s);
             HIP_TRY(launch_layernorm(w.x, h->ptr<float>(h->norm_g), h->ptr<float>(h->norm_b),
                                      io->out_feat + (size_t)slot * T * h->D, false, T, h->D, h->cfg.ln_eps, s));
+        }
     }
     if (fl & OCM_OUT_TOKENS)
         HIP_TRY(hipMemcpyAsync(io->out_tokens, w.x, T * h->D * 4, hipMemcpyDeviceToDevice, s));

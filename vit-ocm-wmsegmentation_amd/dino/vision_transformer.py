@@ -1,0 +1,408 @@
+"""Drop-in module surface of the reference's `dino/vision_transformer.py`, executed by the
+gfx950 HIP engine (libocm_vit.so) instead of ATen.
+
+What is kept: the factories `vit_tiny/vit_small/vit_base(patch_size, **kw)`, the
+class names, constructor keywords, attribute names (`patch_embed.proj`, `cls_token`, `pos_embed`,
+`pos_drop`, `blocks`, `norm`, `head`, `embed_dim`, `num_features`), the state_dict keys and the
+method signatures / return conventions of `VisionTransformer`
+(reference dino/vision_transformer.py:135-256), so eval.py:60-77,136, sw_processing.py:181-239,
+analyse_attention.py:55-116 and the subclasses in model.py:11-53,110-139 bind unchanged.
+
+What is different: the nn.Linear / nn.Conv2d / nn.LayerNorm children are parameter containers.
+No forward below calls their ATen kernels; every method packs device pointers and calls the C ABI
+(include/ocm_vit.h). Inputs must be on a HIP device — there is deliberately no CPU fallback
+(the CPU statement of this arithmetic is the test oracle under oracle/).
+"""
+import ctypes as C
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..engine import Engine, _p, _require_hip, _stream
+from .utils import trunc_normal_
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _Bf16Cache:
+    """bf16 copy of an fp32 matrix parameter for the stand-alone operator paths."""
+
+    def __init__(self):
+        self.key, self.val = None, None
+
+    def get(self, param):
+        key = (param.data_ptr(), param._version, param.device)
+        if key != self.key:
+            src = _f32c(param)
+            dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
+            _lib.check(_lib.load().ocm_op_cast_bf16(_p(src), _p(dst), src.numel(), _stream()))
+            self.key, self.val = key, dst
+        return self.val
+
+
+def _cast_bf16(x32):
+    out = torch.empty(x32.shape, dtype=torch.bfloat16, device=x32.device)
+    _lib.check(_lib.load().ocm_op_cast_bf16(_p(x32), _p(out), x32.numel(), _stream()))
+    return out
+
+
+def _bias_or_zeros(linear):
+    if linear.bias is not None:
+        return _f32c(linear.bias)
+    return torch.zeros(linear.out_features, dtype=torch.float32, device=linear.weight.device)
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm parameter container whose forward runs ocm_op_layernorm (fp32 out)."""
+
+    def forward(self, x):
+        _require_hip(x, "LayerNorm input")
+        x32 = _f32c(x)
+        y = torch.empty_like(x32)
+        dim = x32.shape[-1]
+        with torch.cuda.device(x32.device):
+            _lib.check(_lib.load().ocm_op_layernorm(_p(x32), _p(_f32c(self.weight)), _p(_f32c(self.bias)), _p(y), 0,
+                                                    x32.numel() // dim, dim, float(self.eps), _stream()))
+        return y
+
+
+class Mlp(nn.Module):
+    """fc2(GELU_erf(fc1(x))) — reference Mlp (:47-63). Dropout is p=0 in every reference config."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+        self.drop = nn.Dropout(drop)
+        self._w = (_Bf16Cache(), _Bf16Cache())
+
+    def forward(self, x):
+        _require_hip(x, "Mlp input")
+        lib = _lib.load()
+        shape = x.shape
+        x32 = _f32c(x).reshape(-1, shape[-1])
+        rows, hid, out_f = x32.shape[0], self.fc1.out_features, self.fc2.out_features
+        with torch.cuda.device(x32.device):
+            a = _cast_bf16(x32)
+            h = torch.empty((rows, hid), dtype=torch.bfloat16, device=x32.device)
+            _lib.check(lib.ocm_op_linear(_p(a), _p(self._w[0].get(self.fc1.weight)), _p(_bias_or_zeros(self.fc1)), None,
+                                         _p(h), rows, hid, shape[-1], _lib.OCM_EPI_BIAS_GELU_BF16, _stream()))
+            y = torch.empty((rows, out_f), dtype=torch.float32, device=x32.device)
+            _lib.check(lib.ocm_op_linear(_p(h), _p(self._w[1].get(self.fc2.weight)), _p(_bias_or_zeros(self.fc2)), None,
+                                         _p(y), rows, out_f, hid, _lib.OCM_EPI_BIAS_F32, _stream()))
+        return y.reshape(*shape[:-1], out_f)
+
+
+class Attention(nn.Module):
+    """Multi-head self-attention returning (x, attn, qkv) — reference Attention (:66-90)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        self._w = (_Bf16Cache(), _Bf16Cache())
+
+    def forward(self, x, return_qkv=False):
+        _require_hip(x, "Attention input")
+        lib = _lib.load()
+        B, N, Cd = x.shape
+        H = self.num_heads
+        if Cd != H * 64:
+            raise ValueError("the HIP attention kernels need head_dim == 64")
+        x32 = _f32c(x).reshape(B * N, Cd)
+        dev, npad = x32.device, lib.ocm_n_pad(N)
+        with torch.cuda.device(dev):
+            a = _cast_bf16(x32)
+            q = torch.empty((B * H, npad, 64), dtype=torch.bfloat16, device=dev)
+            k = torch.empty_like(q)
+            vt = torch.empty((B * H, 64, npad), dtype=torch.bfloat16, device=dev)
+            qkv = torch.empty((3, B, H, N, 64), dtype=torch.float32, device=dev)
+            _lib.check(lib.ocm_op_qkv_proj(_p(a), _p(self._w[0].get(self.qkv.weight)), _p(_bias_or_zeros(self.qkv)),
+                                           _p(q), _p(k), _p(vt), _p(qkv), B, N, H, _stream()))
+            ctx = torch.empty((B * N, Cd), dtype=torch.bfloat16, device=dev)
+            lse = torch.empty((B * H, N), dtype=torch.float32, device=dev)
+            _lib.check(lib.ocm_op_attention(_p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, float(self.scale), _stream()))
+            attn = torch.empty((B, H, N, N), dtype=torch.float32, device=dev)
+            _lib.check(lib.ocm_op_attention_probs(_p(q), _p(k), _p(lse), _p(attn), B, N, H, float(self.scale), _stream()))
+            y = torch.empty((B * N, Cd), dtype=torch.float32, device=dev)
+            _lib.check(lib.ocm_op_linear(_p(ctx), _p(self._w[1].get(self.proj.weight)), _p(_bias_or_zeros(self.proj)),
+                                         None, _p(y), B * N, Cd, Cd, _lib.OCM_EPI_BIAS_F32, _stream()))
+        return y.reshape(B, N, Cd), attn, qkv
+
+
+class Block(nn.Module):
+    """Pre-norm transformer block — reference Block (:94-114)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = _make_norm(norm_layer, dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop,
+                              proj_drop=drop)
+        self.drop_path = nn.Identity()
+        self._drop_rates = (drop, attn_drop, drop_path)
+        self.norm2 = _make_norm(norm_layer, dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x, return_attention=False, return_qkv=False):
+        owner = self.__dict__.get("_owner")
+        if owner is not None:  # the block of a VisionTransformer: one fused engine call
+            return owner[0]._block_forward(self.__dict__["_index"], x, return_attention, return_qkv)
+        # free-standing block: same kernels through the stand-alone operators
+        y, attn, qkv = self.attn(self.norm1(x))
+        if return_attention:
+            return attn
+        x = _f32c(x) + y
+        x = x + self.mlp(self.norm2(x))
+        return (x, attn, qkv) if return_qkv else x
+
+
+class PatchEmbed(nn.Module):
+    """Image to patch embedding — reference PatchEmbed (:117-132): Conv2d(k=p, s=p), row-major
+    flatten, token-major output (B, P, D)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.num_patches = (img_size // patch_size) * (img_size // patch_size)
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+
+    def forward(self, x):
+        owner = self.__dict__.get("_owner")
+        if owner is None:
+            raise RuntimeError("PatchEmbed runs through its VisionTransformer's HIP engine; a free-standing "
+                               "PatchEmbed has no engine to call")
+        return owner[0]._patch_embed_only(x)
+
+
+def _make_norm(norm_layer, dim):
+    probe = norm_layer(dim)
+    if not isinstance(probe, nn.LayerNorm) or not probe.elementwise_affine:
+        raise NotImplementedError("the HIP engine implements affine nn.LayerNorm only")
+    return LayerNorm(dim, eps=probe.eps)
+
+
+class VisionTransformer(nn.Module):
+    """Vision Transformer — reference VisionTransformer (:135-256)."""
+
+    def __init__(self, img_size=[224], patch_size=16, in_chans=3, num_classes=0, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., norm_layer=nn.LayerNorm, **kwargs):
+        super().__init__()
+        self.num_features = self.embed_dim = embed_dim
+        self.patch_embed = PatchEmbed(img_size=img_size[0], patch_size=patch_size, in_chans=in_chans,
+                                      embed_dim=embed_dim)
+        n0 = self.patch_embed.num_patches + 1
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n0, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        rates = torch.linspace(0, drop_path_rate, depth).tolist()
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate, drop_path=rates[i], norm_layer=norm_layer)
+            for i in range(depth)])
+        self.norm = _make_norm(norm_layer, embed_dim)
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+        trunc_normal_(self.pos_embed, std=.02)
+        trunc_normal_(self.cls_token, std=.02)
+        self.apply(self._init_weights)
+
+        # engine-side state (never part of the state_dict)
+        self._hyper = dict(patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim, depth=depth,
+                           num_heads=num_heads, mlp_hidden=int(embed_dim * mlp_ratio), ln_eps=float(self.norm.eps),
+                           qk_scale=float(qk_scale or (embed_dim // num_heads) ** -0.5))
+        self._drop_any = max(drop_rate, attn_drop_rate, drop_path_rate) > 0
+        self.__dict__["_engines"] = {}
+        self.__dict__["_pos_cache"] = {}
+        self.__dict__["_gray_fold"] = False
+        for i, blk in enumerate(self.blocks):
+            blk.__dict__["_owner"] = (self,)
+            blk.__dict__["_index"] = i
+        self.patch_embed.__dict__["_owner"] = (self,)
+
+    def _init_weights(self, m):
+        # reference :167-174 — Linear: trunc-normal(.02) weight, zero bias; LayerNorm: (1, 0)
+        if isinstance(m, nn.Linear):
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_engines"], st["_pos_cache"] = {}, {}
+        return st
+
+    # ---- engine management ------------------------------------------------------------------
+    def enable_grayscale_fold(self, on=True):
+        """OCM tiles are grayscale replicated to RGB (data.py:27,68). With the fold on, the patch
+        embedding reads ONE plane and uses W.sum(dim=1): pass (B,1,H,W) tiles, or
+        (B,3,H,W) tiles whose planes are identical (only plane 0 is read)."""
+        if self.patch_embed.proj.in_channels != 3 and on:
+            raise ValueError("grayscale fold applies to a 3-channel patch embedding")
+        self.__dict__["_gray_fold"] = bool(on)
+        self.__dict__["_engines"] = {}
+        return self
+
+    def _named_engine_params(self):
+        skip = ("pos_embed", "head.", "mask_token")
+        return [(n, p) for n, p in self.named_parameters() if not n.startswith(skip)]
+
+    def _engine(self, device):
+        if self.training and self._drop_any:
+            raise NotImplementedError("dropout / drop-path > 0 in training mode is outside the inference hot path")
+        named = self._named_engine_params()
+        sig = tuple((p.data_ptr(), p._version) for _, p in named)
+        ent = self._engines.get(device)
+        if ent is not None and ent[1] == sig:
+            return ent[0]
+        for _, p in named:
+            if p.device != device:
+                raise RuntimeError(f"parameters are on {p.device} but the input is on {device}; call model.to(device)")
+        hy = dict(self._hyper)
+        if self._gray_fold:
+            hy["in_chans"] = 1
+        eng = ent[0] if ent is not None else Engine(device=device, **hy)
+        have = set()
+        for name, p in named:
+            eng.set_param(name, p)
+            have.add(name)
+        zeros = {}
+        for i, blk in enumerate(self.blocks):  # qkv_bias=False etc.: the engine always adds a bias
+            for sub, lin in (("attn.qkv", blk.attn.qkv), ("attn.proj", blk.attn.proj), ("mlp.fc1", blk.mlp.fc1),
+                             ("mlp.fc2", blk.mlp.fc2)):
+                key = f"blocks.{i}.{sub}.bias"
+                if key not in have:
+                    z = zeros.setdefault(lin.out_features, torch.zeros(lin.out_features, device=device))
+                    eng.set_param(key, z)
+        if self.patch_embed.proj.bias is None:
+            eng.set_param("patch_embed.proj.bias", torch.zeros(self.embed_dim, device=device))
+        self._engines[device] = (eng, sig)
+        return eng
+
+    def _pos_for(self, npatch, w, h, device):
+        """(N, D) fp32 positional table for a w x h pixel tile, on `device`, cached per shape."""
+        key = (npatch, w, h, device, self.pos_embed.data_ptr(), self.pos_embed._version)
+        pos = self._pos_cache.get(key)
+        if pos is None:
+            pos = self._interpolated_pos(npatch, w, h)[0].to(device=device, dtype=torch.float32).contiguous()
+            self.__dict__["_pos_cache"] = {key: pos}
+        return pos
+
+    def _interpolated_pos(self, npatch, w, h):
+        """reference interpolate_pos_encoding (:176-196), evaluated once per tile shape on the host
+        (it does not depend on pixel values): identity for the native square grid, otherwise bicubic
+        resampling of the sqrt(N0) x sqrt(N0) grid with the +0.1 scale-factor trick."""
+        pos = self.pos_embed.detach().float().cpu()
+        n0 = pos.shape[1] - 1
+        if npatch == n0 and w == h:
+            return pos
+        dim = pos.shape[-1]
+        side = int(math.sqrt(n0))
+        w0 = w // self.patch_embed.patch_size + 0.1
+        h0 = h // self.patch_embed.patch_size + 0.1
+        grid = pos[:, 1:].reshape(1, side, side, dim).permute(0, 3, 1, 2)
+        grid = nn.functional.interpolate(grid, scale_factor=(w0 / math.sqrt(n0), h0 / math.sqrt(n0)), mode="bicubic")
+        assert int(w0) == grid.shape[-2] and int(h0) == grid.shape[-1]
+        grid = grid.permute(0, 2, 3, 1).reshape(1, -1, dim)
+        return torch.cat((pos[:, :1], grid), dim=1)
+
+    def _check_input(self, x):
+        _require_hip(x, "input")
+        if x.dim() != 4:
+            raise ValueError(f"expected (B, C, H, W) input, got {tuple(x.shape)}")
+        p = self.patch_embed.patch_size
+        if x.shape[-2] % p or x.shape[-1] % p:
+            raise ValueError(f"input {tuple(x.shape[-2:])} is not a multiple of patch_size {p}")
+        x = x.detach()
+        if x.dtype != torch.float32:
+            x = x.float()
+        if self._gray_fold and x.shape[1] == 3:
+            x = x[:, :1]
+        return x
+
+    def _run(self, x, **kw):
+        x = self._check_input(x)
+        eng = self._engine(x.device)
+        w, h = x.shape[-2], x.shape[-1]
+        npatch = (w // eng.p) * (h // eng.p)
+        return eng.forward(x, self._pos_for(npatch, w, h, x.device), **kw)
+
+    # ---- reference methods ------------------------------------------------------------------
+    def interpolate_pos_encoding(self, x, w, h):
+        return self._interpolated_pos(x.shape[1] - 1, w, h).to(x.device)
+
+    def prepare_tokens(self, x):
+        x = self._check_input(x)
+        eng = self._engine(x.device)
+        w, h = x.shape[-2], x.shape[-1]
+        return eng.prepare_tokens(x, self._pos_for((w // eng.p) * (h // eng.p), w, h, x.device))
+
+    def _patch_embed_only(self, x):
+        x = self._check_input(x)
+        eng = self._engine(x.device)
+        n = eng.n_tokens(x.shape[-2], x.shape[-1])
+        zero_pos = torch.zeros((n, self.embed_dim), dtype=torch.float32, device=x.device)
+        return eng.prepare_tokens(x, zero_pos)[:, 1:]
+
+    def _block_forward(self, index, x, return_attention, return_qkv):
+        _require_hip(x, "block input")
+        eng = self._engine(x.device)
+        xo, attn, qkv = eng.block_forward(index, x, want_attn=return_attention or return_qkv, want_qkv=return_qkv,
+                                          attn_only=return_attention)
+        if return_attention:
+            return attn
+        return (xo, attn, qkv) if return_qkv else xo
+
+    def forward(self, x):
+        return self._run(x, flags=_lib.OCM_OUT_FEAT)["feat"][0][:, 0]
+
+    def forward_feats(self, x):
+        return self._run(x, flags=_lib.OCM_OUT_FEAT)["feat"][0]
+
+    def get_intermediate_feat(self, x, n=1):
+        n = max(1, min(int(n), len(self.blocks)))
+        out = self._run(x, flags=_lib.OCM_OUT_FEAT | _lib.OCM_OUT_ATTN | _lib.OCM_OUT_QKV, n_last=n)
+        return list(out["feat"].unbind(0)), list(out["attn"].unbind(0)), list(out["qkv"].unbind(0))
+
+    def get_last_selfattention(self, x):
+        return self._run(x, flags=_lib.OCM_OUT_ATTN | _lib.OCM_LAST_ATTN_ONLY)["attn"][0]
+
+    def get_intermediate_layers(self, x, n=1):
+        n = max(1, min(int(n), len(self.blocks)))
+        return list(self._run(x, flags=_lib.OCM_OUT_FEAT, n_last=n)["feat"].unbind(0))
+
+    # ---- MI355X-native extension used by the sliding-window driver -------------------------------
+    def get_last_attention_rows(self, x, query_rows=None):
+        """attentions[0][:, :, query, 1:] of the last block for the given token indices (default: CLS)
+        without materialising the (B,H,N,N) matrix: (B, H, n_rows, N-1) fp32."""
+        return self._run(x, flags=_lib.OCM_OUT_ROWS | _lib.OCM_LAST_ATTN_ONLY, query_rows=query_rows)["rows"]
+
+
+def vit_tiny(patch_size=16, **kwargs):
+    return VisionTransformer(patch_size=patch_size, embed_dim=192, depth=12, num_heads=3, mlp_ratio=4, qkv_bias=True,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def vit_small(patch_size=16, **kwargs):
+    return VisionTransformer(patch_size=patch_size, embed_dim=384, depth=12, num_heads=6, mlp_ratio=4, qkv_bias=True,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def vit_base(patch_size=16, **kwargs):
+    return VisionTransformer(patch_size=patch_size, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
+                             norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)

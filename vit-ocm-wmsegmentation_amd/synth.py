@@ -1,0 +1,108 @@
+"""Deterministic synthetic weights and OCM-like tiles.
+
+No trained checkpoint exists offline (reference `checkpoints/model*.pth` are missing blobs, the
+DINO URL fallback of eval.py:80-92 is a network fetch), so parity and throughput are measured
+on synthetic parameters. Every tensor is a pure function of (seed, parameter name, shape) through
+a counter-based generator, so this container, the GPU box and the golden-fixture script all
+regenerate identical values without sharing RNG state with anything else.
+
+Distributions follow the reference's initialisation (dino/vision_transformer.py:163-174):
+Linear / cls / pos ~ N(0, 0.02^2) clamped to [-2, 2] (trunc_normal_ with absolute bounds, i.e.
+effectively untruncated), conv weight/bias ~ U(+-1/sqrt(fan_in)) (PyTorch Conv2d default).
+`variant` widens that so that every parameter matters in a parity test:
+  "init"  : reference init exactly (LayerNorm = (1, 0), Linear biases = 0)
+  "full"  : + random Linear biases N(0, 0.02^2), LayerNorm weight 1 + N(0, 0.1^2), bias N(0, 0.05^2)
+  "sharp" : "full" with attn.qkv weights x4 (peaked attention; random-init attention is nearly
+            uniform, max ~0.006, and hides precision bugs — SURVEY §7-1); attention max ~0.013
+  "peaked": "full" with attn.qkv weights x8: attention max ~0.79, CLS-row max ~0.40 (ViT-S/16) —
+            the precision stress set
+"""
+import zlib
+
+import numpy as np
+import torch
+
+ARCHS = {
+    # name: (embed_dim, depth, num_heads)  — vit_tiny/small/base factories (:259-279)
+    "vit_tiny": (192, 12, 3),
+    "vit_small": (384, 12, 6),
+    "vit_base": (768, 12, 12),
+}
+
+
+def _rng(seed, name):
+    return np.random.Generator(np.random.Philox(key=[int(seed) & 0xFFFFFFFF, zlib.crc32(name.encode())]))
+
+
+def _normal(seed, name, shape, std):
+    v = _rng(seed, name).standard_normal(size=shape, dtype=np.float64) * std
+    return torch.from_numpy(np.clip(v, -2.0, 2.0).astype(np.float32))
+
+
+def _uniform(seed, name, shape, bound):
+    v = _rng(seed, name).uniform(-bound, bound, size=shape)
+    return torch.from_numpy(v.astype(np.float32))
+
+
+def param_shapes(embed_dim, depth, patch_size, in_chans=3, mlp_ratio=4.0, img_size=224):
+    """state_dict key -> shape, identical to the reference module's."""
+    D, M = embed_dim, int(embed_dim * mlp_ratio)
+    n0 = (img_size // patch_size) ** 2 + 1
+    shapes = {
+        "cls_token": (1, 1, D),
+        "pos_embed": (1, n0, D),
+        "patch_embed.proj.weight": (D, in_chans, patch_size, patch_size),
+        "patch_embed.proj.bias": (D,),
+    }
+    for i in range(depth):
+        b = f"blocks.{i}."
+        shapes.update({
+            b + "norm1.weight": (D,), b + "norm1.bias": (D,),
+            b + "attn.qkv.weight": (3 * D, D), b + "attn.qkv.bias": (3 * D,),
+            b + "attn.proj.weight": (D, D), b + "attn.proj.bias": (D,),
+            b + "norm2.weight": (D,), b + "norm2.bias": (D,),
+            b + "mlp.fc1.weight": (M, D), b + "mlp.fc1.bias": (M,),
+            b + "mlp.fc2.weight": (D, M), b + "mlp.fc2.bias": (D,),
+        })
+    shapes.update({"norm.weight": (D,), "norm.bias": (D,)})
+    return shapes
+
+
+def synth_state_dict(embed_dim, depth, patch_size, *, seed=0, variant="full", in_chans=3, mlp_ratio=4.0,
+                     img_size=224):
+    if variant not in ("init", "full", "sharp", "peaked"):
+        raise ValueError(f"unknown variant {variant!r}")
+    sd = {}
+    for name, shape in param_shapes(embed_dim, depth, patch_size, in_chans, mlp_ratio, img_size).items():
+        if name.startswith("patch_embed.proj"):
+            fan_in = in_chans * patch_size * patch_size
+            t = _uniform(seed, name, shape, 1.0 / np.sqrt(fan_in))
+        elif ".norm" in name or name.startswith("norm."):
+            if variant == "init":
+                t = torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
+            elif name.endswith("weight"):
+                t = 1.0 + _normal(seed, name, shape, 0.1)
+            else:
+                t = _normal(seed, name, shape, 0.05)
+        elif name.endswith(".bias"):
+            t = torch.zeros(shape) if variant == "init" else _normal(seed, name, shape, 0.02)
+        else:
+            t = _normal(seed, name, shape, 0.02)
+            if variant in ("sharp", "peaked") and name.endswith("attn.qkv.weight"):
+                t = t * (4.0 if variant == "sharp" else 8.0)
+        sd[name] = t
+    return sd
+
+
+def synth_arch_state_dict(arch, patch_size, **kw):
+    D, L, _ = ARCHS[arch]
+    return synth_state_dict(D, L, patch_size, **kw)
+
+
+def synth_tiles(batch, height, width=None, *, seed=1234, channels=3):
+    """Grayscale OCM-like tiles replicated to RGB, fp32 in [0, 0.3) (real tiles have
+    R == G == B, mean ~0.145; ToTensor only, no mean/std normalisation — data.py:291-299)."""
+    width = height if width is None else width
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.rand(batch, 1, height, width, generator=g) * 0.3
+    return x1.expand(-1, channels, -1, -1).contiguous() if channels > 1 else x1
