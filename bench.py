@@ -52,12 +52,27 @@ def class_flops(D, M, N, B, p, in_chans):
     }
 
 
+def host_cores():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box
+    exposes every core of the host but grants a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    if "OCM_CPU_THREADS" in os.environ:
+        n = int(os.environ["OCM_CPU_THREADS"])
+    return n
+
+
 def cpu_baseline(arch_dims, patch, size, batch, seconds_budget=20.0):
     """The oracle (CPU restatement of the reference, fp32 torch-CPU ops) timed on this host."""
     from oracle import vit_oracle as O  # CPU baseline leg: allowed importer of oracle/
     from vit_ocm_wmsegmentation_amd import synth
     D, L, H = arch_dims
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     torch.set_num_threads(cores)
     sd = synth.synth_state_dict(D, L, patch, seed=0, variant="init")
     cfg = O.make_cfg(sd, patch, H)
