@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Per-kernel microbenchmark at the bench shapes (ViT-S/16, B=64 by default): times each stand-alone
+operator of the C ABI with torch.cuda events on the launch stream. Development tool (GPU box only).
+
+    python tools/microbench.py [--batch 64] [--dim 384] [--tokens 197] [--iters 50] [--only name,...]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from vit_ocm_wmsegmentation_amd import _lib  # noqa: E402
+
+
+def p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def timeit(fn, iters):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--tokens", type=int, default=197)
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--lin", default="", help="extra linear shapes 'M,N,K,epi;M,N,K,epi'")
+    a = ap.parse_args()
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    B, D, N = a.batch, a.dim, a.tokens
+    H, M, T = D // 64, 4 * D, B * N
+    only = set(filter(None, a.only.split(",")))
+    g = torch.Generator().manual_seed(0)
+
+    def rnd(*shape, scale=1.0, dtype=torch.bfloat16):
+        return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+    x32 = rnd(T, D, dtype=torch.float32)
+    xn = rnd(T, D)
+    hid = rnd(T, M)
+    w_qkv, w_proj, w_fc1, w_fc2 = rnd(3 * D, D, scale=.02), rnd(D, D, scale=.02), rnd(M, D, scale=.02), rnd(D, M, scale=.02)
+    b_qkv, b_d, b_m = (rnd(3 * D, dtype=torch.float32), rnd(D, dtype=torch.float32), rnd(M, dtype=torch.float32))
+    gam, bet = rnd(D, dtype=torch.float32), rnd(D, dtype=torch.float32)
+    npad = lib.ocm_n_pad(N)
+    q = rnd(B * H, npad, 64)
+    k = rnd(B * H, npad, 64)
+    vt = rnd(B * H, 64, npad)
+    ctx = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
+    lse = torch.empty((B * H, N), dtype=torch.float32, device=dev)
+    attn = torch.empty((B, H, N, N), dtype=torch.float32, device=dev)
+    out_h = torch.empty((T, M), dtype=torch.bfloat16, device=dev)
+    xn_out = torch.empty((T, D), dtype=torch.bfloat16, device=dev)
+
+    tests = {
+        "layernorm": (lambda: lib.ocm_op_layernorm(p(x32), p(gam), p(bet), p(xn_out), 1, T, D, 1e-6, s()), 0,
+                      T * D * 6),
+        "qkv": (lambda: lib.ocm_op_qkv_proj(p(xn), p(w_qkv), p(b_qkv), p(q), p(k), p(vt), None, B, N, H, s()),
+                2.0 * T * D * 3 * D, 0),
+        "attention": (lambda: lib.ocm_op_attention(p(q), p(k), p(vt), p(ctx), None, B, N, H, 0.125, s()),
+                      4.0 * B * N * N * D, 0),
+        "attention_lse": (lambda: lib.ocm_op_attention(p(q), p(k), p(vt), None, p(lse), B, N, H, 0.125, s()),
+                          2.0 * B * N * N * D, 0),
+        "probs": (lambda: lib.ocm_op_attention_probs(p(q), p(k), p(lse), p(attn), B, N, H, 0.125, s()),
+                  2.0 * B * N * N * D, B * H * N * N * 4),
+        "proj": (lambda: lib.ocm_op_linear(p(xn), p(w_proj), p(b_d), p(x32), p(x32), T, D, D, 1, s()), 2.0 * T * D * D,
+                 T * D * 10),
+        "fc1": (lambda: lib.ocm_op_linear(p(xn), p(w_fc1), p(b_m), None, p(out_h), T, M, D, 2, s()), 2.0 * T * D * M,
+                T * (D + M) * 2),
+        "fc1_nogelu": (lambda: lib.ocm_op_linear(p(xn), p(w_fc1), p(b_m), None, p(out_h), T, M, D, 3, s()),
+                       2.0 * T * D * M, T * (D + M) * 2),
+        "fc1_mainloop_only": (lambda: lib.ocm_op_linear(p(xn), p(w_fc1), p(b_m), None, p(out_h), T, M, D, 100, s()),
+                              2.0 * T * D * M, 0),
+        "fc2_mainloop_only": (lambda: lib.ocm_op_linear(p(hid), p(w_fc2), p(b_d), None, p(x32), T, D, M, 100, s()),
+                              2.0 * T * D * M, 0),
+        "fc2": (lambda: lib.ocm_op_linear(p(hid), p(w_fc2), p(b_d), p(x32), p(x32), T, D, M, 1, s()), 2.0 * T * D * M,
+                T * (M * 2 + D * 8)),
+    }
+    for spec in filter(None, a.lin.split(";")):
+        m_, n_, k_, e_ = map(int, spec.split(","))
+        la, lw, lb = rnd(m_, k_), rnd(n_, k_, scale=.02), rnd(n_, dtype=torch.float32)
+        lo = torch.empty((m_, n_), dtype=torch.float32, device=dev)
+        tests[f"lin{spec}"] = ((lambda la=la, lw=lw, lb=lb, lo=lo, m_=m_, n_=n_, k_=k_, e_=e_:
+                                lib.ocm_op_linear(p(la), p(lw), p(lb), p(lo), p(lo), m_, n_, k_, e_, s())),
+                               2.0 * m_ * n_ * k_, 0)
+        only.add(f"lin{spec}") if only else None
+    print(f"B={B} D={D} N={N} T={T}")
+    for name, (fn, flops, bytes_) in tests.items():
+        if only and name not in only:
+            continue
+        rc = fn()
+        assert rc == 0, lib.ocm_last_error()
+        us = timeit(fn, a.iters)
+        msg = f"{name:14s} {us:8.2f} us"
+        if flops:
+            msg += f"  {flops / us / 1e6:8.1f} TFLOP/s"
+        if bytes_:
+            msg += f"  {bytes_ / us / 1e6:6.2f} TB/s"
+        print(msg)
+
+
+if __name__ == "__main__":
+    main()

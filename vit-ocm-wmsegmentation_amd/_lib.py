@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libocm_vit.so")
+# OCM_VIT_LIB lets kernel experiments A/B two builds of the same ABI; the default is the in-tree build.
+LIB_PATH = os.environ.get("OCM_VIT_LIB") or os.path.join(_HERE, "libocm_vit.so")
 
 OCM_ABI_VERSION = 1
 OCM_OK, OCM_EINVAL, OCM_ESTATE, OCM_EHIP, OCM_ENOMEM, OCM_ENAME = 0, 1, 2, 3, 4, 5

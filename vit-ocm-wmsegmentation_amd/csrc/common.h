@@ -27,6 +27,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// Workgroup barrier that orders LDS traffic only: `s_waitcnt lgkmcnt(0); s_barrier`. Unlike
+// __syncthreads() it does not drain the vector-memory counter, so global prefetches and epilogue
+// stores stay in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
@@ -45,4 +54,39 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. fp32-grade) on the hardware
+// reciprocal / exp2 units: ~12 VALU ops instead of libm erff's ~50, which made the fc1 epilogue
+// cost more than its MFMA main loop.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = fmaf(-p * t, e, 1.0f);
+    return copysignf(r, x);
+}
+// Two GELUs at once on packed fp32 (v_pk_fma_f32 / v_pk_mul_f32): with erf(z) = 1 - P(t) e^{-z^2} (z >= 0)
+//   gelu(x) = max(x, 0) - 0.5 |x| P(t) exp(-x^2 / 2),   t = 1 / (1 + p |x| / sqrt(2))
+// (same A&S 7.1.26 coefficients as erf_as, the 0.5 folded in), ~10 VALU ops per element.
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+    const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2 den = ax * 0.2316418882f + 1.0f;  // p / sqrt(2)
+    const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    f32x2 p = t * 0.5307027145f + (-0.7265760135f);  // a5 / 2, a4 / 2
+    p = p * t + 0.7107068705f;                       // a3 / 2
+    p = p * t + (-0.142248368f);                     // a2 / 2
+    p = p * t + 0.127414796f;                        // a1 / 2
+    p = p * t;
+    const f32x2 u = x * 0.8493218003f;  // sqrt(log2(e) / 2)
+    const f32x2 nu2 = -(u * u);
+    const f32x2 e = {__builtin_amdgcn_exp2f(nu2[0]), __builtin_amdgcn_exp2f(nu2[1])};
+    const f32x2 g = ax * p * e;
+    const f32x2 r = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    return r - g;
+}
+
+// GELU(approximate='none') of the reference (nn.GELU, dino/vision_transformer.py:53)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }

@@ -432,7 +432,7 @@ extern "C" int ocm_op_linear(const void *a, const void *w, const float *bias, co
                              int32_t M, int32_t N, int32_t K, int32_t epilogue, void *stream) {
     if (!a || !w || !out) return fail(OCM_EINVAL, "null argument");
     if (M <= 0 || N <= 0 || N % 32 || K <= 0 || K % 64) return fail(OCM_EINVAL, "bad shape M=%d N=%d K=%d (N%%32, K%%64)", M, N, K);
-    if (epilogue < 0 || epilogue > 3) return fail(OCM_EINVAL, "bad epilogue %d", epilogue);
+    if ((epilogue < 0 || epilogue > 3) && epilogue != 100) return fail(OCM_EINVAL, "bad epilogue %d", epilogue);
     if (epilogue == OCM_EPI_BIAS_RESID_F32 && !resid) return fail(OCM_EINVAL, "residual epilogue without resid");
     HIP_TRY(launch_linear((const bf16 *)a, (const bf16 *)w, bias, resid, out, M, N, K, epilogue, (hipStream_t)stream));
     return OCM_OK;

@@ -96,10 +96,12 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const bf16 *__res
     const int nt = K >> 6;
     issue(0);
     commit(0);
-    __syncthreads();
+    lds_barrier();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
+#if !defined(TILE_EXP) || TILE_EXP != 6
         if (t + 1 < nt) issue((t + 1) << 6);
+#endif
         const char *Ab = As + buf * BM * 128 + (wm * Cfg::WM) * 128;
         const char *Bb = Bs + buf * BN * 128 + (wn * Cfg::WN) * 128;
 #pragma unroll
@@ -115,11 +117,40 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const bf16 *__res
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
+#if defined(TILE_EXP) && TILE_EXP == 5
+                    if (i + j + s == 0)
+#endif
                     acc[i][j] = SWAP ? mfma32(b[j], a[i], acc[i][j]) : mfma32(a[i], b[j], acc[i][j]);
         }
         if (t + 1 < nt) commit(buf ^ 1);
-        __syncthreads();
+        lds_barrier();
     }
+}
+
+// Epilogue staging: after the main loop's last barrier the operand LDS is free, so every wave
+// drops its fp32 accumulator tiles into a row-major [ROWS][COLS] LDS image (ROWS x COLS = BM x BN,
+// or BN x BM when the accumulator is transposed). The epilogues then read whole 16-B / 32-B row
+// chunks back and issue full-width, fully coalesced global loads/stores with the index math done
+// once per chunk instead of once per element.
+template <class Cfg, bool SWAP>
+__device__ __forceinline__ void stage_acc(const f32x16 (&acc)[Cfg::TM][Cfg::TN], char *smem) {
+    static_assert(Cfg::BM * Cfg::BN * 4 <= Cfg::LDS_BYTES, "C tile must fit the operand LDS");
+    constexpr int COLS = SWAP ? Cfg::BM : Cfg::BN;
+    float *C = (float *)smem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < Cfg::TN; ++j) {
+            const int tm = wm * Cfg::WM + 32 * i, tn = wn * Cfg::WN + 32 * j;
+            // normal: lane -> column n, registers -> rows m.  swapped: lane -> m, registers -> n.
+            const int row0 = SWAP ? tn : tm, col = (SWAP ? tm : tn) + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) C[(row0 + acc_row32(e, h)) * COLS + col] = acc[i][j][e];
+        }
+    lds_barrier();
 }
 
 // Generic kernel: grid = tiles_m * tiles_n workgroups (linear, XCD-remapped so the
@@ -134,11 +165,6 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const bf16 *__r
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
     gemm_mainloop<Cfg, SWAP>(al, W, ldw, m0, n0, M, N, K, smem, acc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
-#pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < Cfg::TN; ++j)
-            epi(acc[i][j], m0 + wm * Cfg::WM + 32 * i, n0 + wn * Cfg::WN + 32 * j, lane);
+    stage_acc<Cfg, SWAP>(acc, smem);
+    epi.template run<Cfg>((const float *)smem, m0, n0);
 }

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
 
     issue(0);
     commit(0);
-    __syncthreads();
+    lds_barrier();
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < ntiles) issue(kt + 1);
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
             }
         }
         if (kt + 1 < ntiles) commit(buf ^ 1);
-        __syncthreads();
+        lds_barrier();
     }
 
     if (!active) return;

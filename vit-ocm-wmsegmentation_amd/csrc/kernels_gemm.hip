@@ -4,12 +4,18 @@
 //   proj / fc2 + residual (Attention.forward :88, Block.forward :110-111, Mlp.forward :61)
 //   fc1 + exact-erf GELU  (Mlp.forward :58-59)
 // All share gemm_core.h's main loop; they differ in the A loader and the epilogue.
+#include <stdlib.h>
+#include <string.h>
+
 #include "gemm_core.h"
+#include "gemm_panel.h"
 #include "launch.h"
 
 // ------------------------------------------------------------------------------------------
 // nn.Linear epilogues
 // ------------------------------------------------------------------------------------------
+// out = epilogue(acc + bias). fp32 outputs move 16 B (4 columns) per lane, bf16 outputs 16 B
+// (8 columns) per lane; `resid` may alias `out` (each element is read then written by one lane).
 template <int MODE>
 struct EpiLinear {
     const float *bias;
@@ -17,20 +23,39 @@ struct EpiLinear {
     void *out;
     int M, N;
     int64_t ldo;
-    __device__ __forceinline__ void operator()(const f32x16 &acc, int mb, int nb, int lane) const {
-        if (nb >= N || mb >= M) return;
-        const int n = nb + (lane & 31), h = lane >> 5;
-        const float bv = bias ? bias[n] : 0.f;
+    template <class Cfg>
+    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
+        constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
+        constexpr bool OUT_BF16 = (MODE == 2 || MODE == 3);
+        constexpr int W = OUT_BF16 ? 8 : 4;  // columns per lane
+        constexpr int CPR = BN / W;          // chunks per row
+#pragma unroll 4
+        for (int q = threadIdx.x; q < BM * CPR; q += NT) {
+            const int row = q / CPR, col = (q - row * CPR) * W;
+            const int m = m0 + row, n = n0 + col;
+            if (m >= M || n >= N) continue;
+            const int64_t o = (int64_t)m * ldo + n;
+            f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
+            if (bias) v0 += *(const f32x4 *)(bias + n);
+            if (!OUT_BF16) {
+                if (MODE == 1) v0 += *(const f32x4 *)(resid + o);
+                if (MODE == 100) {
+                    if (v0[0] == 123456.789f) *(f32x4 *)((float *)out + o) = v0;  // experiment: main loop only
+                } else {
+                    *(f32x4 *)((float *)out + o) = v0;
+                }
+            } else {
+                f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4);
+                if (bias) v1 += *(const f32x4 *)(bias + n + 4);
+                if (MODE == 2) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int m = mb + acc_row32(reg, h);
-            if (m < M) {
-                const int64_t o = (int64_t)m * ldo + n;
-                const float v = acc[reg] + bv;
-                if (MODE == 0) ((float *)out)[o] = v;
-                if (MODE == 1) ((float *)out)[o] = resid[o] + v;
-                if (MODE == 2) ((bf16 *)out)[o] = (bf16)gelu_erf(v);
-                if (MODE == 3) ((bf16 *)out)[o] = (bf16)v;
+                    for (int e = 0; e < 4; e += 2) {
+                        const f32x2 a = gelu_erf2(f32x2{v0[e], v0[e + 1]}), b = gelu_erf2(f32x2{v1[e], v1[e + 1]});
+                        v0[e] = a[0]; v0[e + 1] = a[1];
+                        v1[e] = b[0]; v1[e + 1] = b[1];
+                    }
+                }
+                *(bf16x8 *)((bf16 *)out + o) = cvt8(v0, v1);
             }
         }
     }
@@ -52,6 +77,219 @@ static hipError_t launch_gemm(const ALoad &al, const bf16 *w, int64_t ldw, int M
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// row-panel GEMM (gemm_panel.h) epilogues
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void panel_stage(const f32x16 (&acc)[2], float *slab, int lane) {
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) slab[acc_row32(e, h) * PANEL_CPAD + 32 * jn + r] = acc[jn][e];
+}
+
+template <int MODE>
+struct PanelEpiLinear {
+    const float *bias;
+    const float *resid;
+    void *out;
+    int M, N;
+    int64_t ldo;
+    __device__ __forceinline__ bool swap_for(int) const { return false; }
+    __device__ __forceinline__ void init(f32x16 (&acc)[2], bool, int n0, int lane) const {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const float bv = bias[n0 + 32 * jn + (lane & 31)];  // lane = output column
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[jn][e] = bv;
+        }
+    }
+    __device__ __forceinline__ void stage(const f32x16 (&acc)[2], bool, float *slab, int lane) const {
+        panel_stage(acc, slab, lane);  // wave-private slab: LDS ops of one wave are ordered, no barrier
+    }
+    struct PartState {
+        f32x4 v0, v1;
+    };
+    // bf16 outputs: quarter p = rows 8p .. 8p+7, one 8-column chunk per lane.
+    // fp32 outputs: quarter p = rows 8p .. 8p+7 as two 4-column chunks per lane (rows 8p+{0..3}, 8p+{4..7}).
+    __device__ __forceinline__ void part_begin(PartState &st, int p, bool, const float *slab, int lane) const {
+        constexpr bool OUT_BF16 = (MODE == 2 || MODE == 3);
+        if (OUT_BF16) {
+            const int q = lane + 64 * p, row = q >> 3, col = (q & 7) * 8;
+            st.v0 = *(const f32x4 *)(slab + row * PANEL_CPAD + col);
+            st.v1 = *(const f32x4 *)(slab + row * PANEL_CPAD + col + 4);
+        } else {
+            const int q0 = lane + 64 * (2 * p), q1 = q0 + 64;
+            st.v0 = *(const f32x4 *)(slab + (q0 >> 4) * PANEL_CPAD + (q0 & 15) * 4);
+            st.v1 = *(const f32x4 *)(slab + (q1 >> 4) * PANEL_CPAD + (q1 & 15) * 4);
+        }
+    }
+    static constexpr bool kHasElem = (MODE == 2);
+    __device__ __forceinline__ void part_elem(PartState &st, int j) const {
+        if (MODE == 2 && (j & 1)) {  // a pair of elements after every second MFMA, on packed fp32
+            f32x4 &v = j < 4 ? st.v0 : st.v1;
+            const int e = (j & 3) - 1;
+            const f32x2 in = {v[e], v[e + 1]};
+            const f32x2 g = gelu_erf2(in);
+            v[e] = g[0];
+            v[e + 1] = g[1];
+        }
+    }
+    __device__ __forceinline__ void part_end(const PartState &st, int p, bool valid, bool, int mw, int n0,
+                                             int lane) const {
+        constexpr bool OUT_BF16 = (MODE == 2 || MODE == 3);
+        if (OUT_BF16) {
+            const int q = lane + 64 * p, row = q >> 3, col = (q & 7) * 8;
+            const int m = mw + row, n = n0 + col;
+            const bf16x8 o = cvt8(st.v0, st.v1);
+            if (valid && m < M) *(bf16x8 *)((bf16 *)out + (int64_t)m * ldo + n) = o;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = lane + 64 * (2 * p + i), row = q >> 4, col = (q & 15) * 4;
+                const int m = mw + row, n = n0 + col;
+                const bool ok = valid && m < M;
+                const int64_t o = (int64_t)(ok ? m : 0) * ldo + n;
+                f32x4 v = i ? st.v1 : st.v0;
+                if (MODE == 1 && ok) v += *(const f32x4 *)(resid + o);
+                if (ok && (MODE != 100 || v[0] == 123456.789f)) *(f32x4 *)((float *)out + o) = v;
+            }
+        }
+    }
+};
+
+struct PanelEpiQKV {
+    const float *bias;
+    bf16 *q, *k, *vt;
+    float *qkv32;
+    int M, ntok, npad, H, D, B;
+    __device__ __forceinline__ bool swap_for(int n0) const { return n0 >= 2 * D; }
+    __device__ __forceinline__ void init(f32x16 (&acc)[2], bool swapped, int n0, int lane) const {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            if (!swapped) {
+                const float bv = bias[n0 + 32 * jn + (lane & 31)];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[jn][e] = bv;
+            } else {  // registers = output column (head-dim index)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[jn][e] = bias[n0 + 32 * jn + acc_row32(e, lane >> 5)];
+            }
+        }
+    }
+    __device__ __forceinline__ void stage(const f32x16 (&acc)[2], bool swapped, float *slab, int lane) const {
+        if (!swapped) {
+            panel_stage(acc, slab, lane);
+        } else {  // transposed accumulator (lane & 31 = token): staged as slab[d][token] (64 x 32)
+            const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) slab[(32 * jn + acc_row32(e, h)) * 32 + r] = acc[jn][e];
+        }
+    }
+    struct PartState {
+        const float *slab;
+    };
+    __device__ __forceinline__ void part_begin(PartState &st, int, bool, const float *slab, int) const { st.slab = slab; }
+    static constexpr bool kHasElem = false;
+    __device__ __forceinline__ void part_elem(PartState &, int) const {}
+    __device__ __forceinline__ void part_end(const PartState &st, int p, bool valid, bool swapped, int mw, int n0,
+                                             int lane) const {
+        const float *slab = st.slab;
+        const int which = n0 / D, head = (n0 - which * D) >> 6;  // a 64-wide tile is exactly one head of q, k or v
+        if (!swapped) {
+            const int qd = lane + 64 * p, row = qd >> 3, col = (qd & 7) * 8;
+            const int m = mw + row;
+            if (!valid || m >= M) return;
+            const int b = m / ntok, t = m - b * ntok;
+            const f32x4 v0 = *(const f32x4 *)(slab + row * PANEL_CPAD + col);
+            const f32x4 v1 = *(const f32x4 *)(slab + row * PANEL_CPAD + col + 4);
+            bf16 *dst = which ? k : q;
+            *(bf16x8 *)(dst + ((int64_t)(b * H + head) * npad + t) * 64 + col) = cvt8(v0, v1);
+            if (qkv32) {
+                float *o = qkv32 + ((((int64_t)which * B + b) * H + head) * ntok + t) * 64 + col;
+                *(f32x4 *)o = v0;
+                *(f32x4 *)(o + 4) = v1;
+            }
+        } else {  // V^T rows: lane & 31 = token (contiguous in vt), the two lane halves take even / odd d
+            const int r = lane & 31, h = lane >> 5, m = mw + r;
+            if (!valid || m >= M) return;
+            const int b = m / ntok, t = m - b * ntok;
+            bf16 *dst = vt + (int64_t)(b * H + head) * 64 * npad + t;
+            float *dst32 = qkv32 ? qkv32 + ((((int64_t)2 * B + b) * H + head) * ntok + t) * 64 : nullptr;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int d = 16 * p + 2 * i + h;
+                const float v = slab[d * 32 + r];
+                dst[(int64_t)d * npad] = (bf16)v;
+                if (dst32) dst32[d] = v;
+            }
+        }
+    }
+};
+
+static int device_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+// The panel kernel serves K in {256, 384} (an even number of 64-deep steps whose A fragments fit
+// the register budget of 2 waves/SIMD) once there are enough rows to amortise the resident A panel.
+static bool panel_ok(int M, int N, int K) {
+    static int mode = -1;  // development switch: OCM_GEMM=tiled disables the panel kernel
+    if (mode < 0) {
+        const char *e = getenv("OCM_GEMM");
+        mode = (e && !strcmp(e, "tiled")) ? 0 : 1;
+    }
+    return mode && (K == 256 || K == 384) && N % 64 == 0 && M >= 512;
+}
+
+template <int KD, int NW, class Epi>
+static hipError_t launch_panel_kd(const bf16 *a, const bf16 *w, int M, int N, const Epi &epi, hipStream_t s) {
+    typedef PanelCfg<NW> PC;
+    auto kern = panel_gemm_kernel<KD, NW, Epi>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PC::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int rbs = (M + PC::BM - 1) / PC::BM, ntiles = N / PANEL_BN;
+    const int slots = device_cus() * (8 / NW);  // 8 waves per CU: one 8-wave or two 4-wave workgroups
+    int nsplit = (slots + rbs / 2) / rbs;       // row_blocks * nsplit ~ resident workgroup slots
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > ntiles) nsplit = ntiles;
+    kern<<<dim3(rbs * nsplit), dim3(PC::NT), PC::LDS_BYTES, s>>>(a, w, M, N, nsplit, epi);
+    return hipGetLastError();
+}
+
+static int panel_waves() {
+    static int nw = 0;
+    if (!nw) {
+        const char *e = getenv("OCM_PANEL_NW");  // development switch
+        nw = (e && atoi(e) == 4) ? 4 : 8;
+    }
+    return nw;
+}
+
+template <class Epi>
+static hipError_t launch_panel(const bf16 *a, const bf16 *w, int M, int N, int K, const Epi &epi, hipStream_t s) {
+    const bool w8 = panel_waves() == 8;
+    switch (K) {
+        case 256: return w8 ? launch_panel_kd<4, 8>(a, w, M, N, epi, s) : launch_panel_kd<4, 4>(a, w, M, N, epi, s);
+        case 384: return w8 ? launch_panel_kd<6, 8>(a, w, M, N, epi, s) : launch_panel_kd<6, 4>(a, w, M, N, epi, s);
+    }
+    return hipErrorInvalidValue;
+}
+
 typedef GemmCfg<128, 128, 2, 2> Cfg128x128;
 typedef GemmCfg<64, 128, 2, 2> Cfg64x128;
 typedef GemmCfg<64, 64, 2, 2> Cfg64x64;
@@ -59,11 +297,19 @@ typedef GemmCfg<64, 64, 2, 2> Cfg64x64;
 template <int MODE>
 static hipError_t launch_linear_mode(const bf16 *a, const bf16 *w, const float *bias, const float *resid, void *out,
                                      int M, int N, int K, hipStream_t s) {
+    if (bias && panel_ok(M, N, K) && N >= 512) {  // wide projections (fc1): A panel resident in registers
+        PanelEpiLinear<MODE> pepi{bias, resid, out, M, N, N};
+        return launch_panel(a, w, M, N, K, pepi, s);
+    }
     RowLoader al{a, K};
     EpiLinear<MODE> epi{bias, resid, out, M, N, N};
     // Tile choice: fill >= 2 workgroups per CU (256 CUs) when the problem allows it.
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const long t64 = (long)((M + 63) / 64) * ((N + 127) / 128);
+    static const char *force = getenv("OCM_TILE");
+    if (N % 128 == 0 && force && !strcmp(force, "128")) return launch_gemm<Cfg128x128, false>(al, w, K, M, N, K, epi, s);
+    if (N % 128 == 0 && force && !strcmp(force, "64")) return launch_gemm<Cfg64x128, false>(al, w, K, M, N, K, epi, s);
+    if (force && !strcmp(force, "6464")) return launch_gemm<Cfg64x64, false>(al, w, K, M, N, K, epi, s);
     if (N % 128 == 0 && t128 >= 512) return launch_gemm<Cfg128x128, false>(al, w, K, M, N, K, epi, s);
     if (N % 128 == 0 && t64 >= 256) return launch_gemm<Cfg64x128, false>(al, w, K, M, N, K, epi, s);
     if (N % 128 == 0 && M > 64) return launch_gemm<Cfg64x128, false>(al, w, K, M, N, K, epi, s);
@@ -77,6 +323,7 @@ hipError_t launch_linear(const bf16 *a, const bf16 *w, const float *bias, const 
         case 1: return launch_linear_mode<1>(a, w, bias, resid, out, M, N, K, s);
         case 2: return launch_linear_mode<2>(a, w, bias, resid, out, M, N, K, s);
         case 3: return launch_linear_mode<3>(a, w, bias, resid, out, M, N, K, s);
+        case 100: return launch_linear_mode<100>(a, w, bias, resid, out, M, N, K, s);
     }
     return hipErrorInvalidValue;
 }
@@ -94,22 +341,25 @@ struct EpiQK {
     bf16 *q, *k;
     float *qkv32;  // optional (3,B,H,N,64) fp32, or nullptr
     int M, ntok, npad, H, D, B;
-    __device__ __forceinline__ void operator()(const f32x16 &acc, int mb, int nb, int lane) const {
-        if (mb >= M) return;
-        const int which = nb / D, rem = nb - which * D;
-        const int head = rem >> 6, d = (rem & 63) + (lane & 31), h = lane >> 5;
-        const float bv = bias[nb + (lane & 31)];
-        bf16 *dst = which ? k : q;
-        const int b0 = mb / ntok, t0 = mb - b0 * ntok;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int dl = acc_row32(reg, h);
-            if (mb + dl < M) {
-                int t = t0 + dl, b = b0;
-                while (t >= ntok) { t -= ntok; ++b; }
-                const float v = acc[reg] + bv;
-                dst[((int64_t)(b * H + head) * npad + t) * 64 + d] = (bf16)v;
-                if (qkv32) qkv32[((((int64_t)which * B + b) * H + head) * ntok + t) * 64 + d] = v;
+    // C is [BM][BN] (rows = tokens). One lane moves 8 consecutive head-dim columns of one token.
+    template <class Cfg>
+    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
+        constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, CPR = BN / 8;
+#pragma unroll 4
+        for (int qd = threadIdx.x; qd < BM * CPR; qd += NT) {
+            const int row = qd / CPR, col = (qd - row * CPR) * 8;
+            const int m = m0 + row, n = n0 + col;
+            if (m >= M) continue;
+            const int which = n / D, rem = n - which * D, head = rem >> 6, d = rem & 63;
+            const int b = m / ntok, t = m - b * ntok;
+            const f32x4 v0 = *(const f32x4 *)(C + row * BN + col) + *(const f32x4 *)(bias + n);
+            const f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4) + *(const f32x4 *)(bias + n + 4);
+            bf16 *dst = which ? k : q;
+            *(bf16x8 *)(dst + ((int64_t)(b * H + head) * npad + t) * 64 + d) = cvt8(v0, v1);
+            if (qkv32) {
+                float *o = qkv32 + ((((int64_t)which * B + b) * H + head) * ntok + t) * 64 + d;
+                *(f32x4 *)o = v0;
+                *(f32x4 *)(o + 4) = v1;
             }
         }
     }
@@ -120,17 +370,20 @@ struct EpiVt {
     bf16 *vt;
     float *qkv32;
     int M, ntok, npad, H, D, B;
-    // acc is transposed: lane & 31 -> token row m, registers -> feature n.
-    __device__ __forceinline__ void operator()(const f32x16 &acc, int mb, int nb, int lane) const {
-        const int m = mb + (lane & 31), h = lane >> 5;
+    // C is the TRANSPOSED tile [BN][BM] (rows = features n, columns = tokens m). Consecutive lanes
+    // take consecutive tokens of one feature row, so each store instruction writes contiguous runs
+    // of V^T (vt[(b*H+head)][d][t], t contiguous).
+    template <class Cfg>
+    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
+        constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
+        const int col = threadIdx.x % BM, m = m0 + col;
         if (m >= M) return;
         const int b = m / ntok, t = m - b * ntok;
-        const int rem = nb - 2 * D, head = rem >> 6, dbase = rem & 63;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int dl = acc_row32(reg, h);
-            const float v = acc[reg] + bias[nb + dl];
-            const int d = dbase + dl;
+        const int rem0 = n0 - 2 * D;
+#pragma unroll 4
+        for (int row = threadIdx.x / BM; row < BN; row += NT / BM) {
+            const int rem = rem0 + row, head = rem >> 6, d = rem & 63;
+            const float v = C[row * BM + col] + bias[n0 + row];
             vt[((int64_t)(b * H + head) * 64 + d) * npad + t] = (bf16)v;
             if (qkv32) qkv32[((((int64_t)2 * B + b) * H + head) * ntok + t) * 64 + d] = v;
         }
@@ -146,21 +399,15 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader al, const bf16 *
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
     f32x16 acc[Cfg::TM][Cfg::TN];
     if (n0 < 2 * D) {  // workgroup-uniform
         gemm_mainloop<Cfg, false>(al, W, K, m0, n0, M, N, K, smem, acc);
-#pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-            for (int j = 0; j < Cfg::TN; ++j) eqk(acc[i][j], m0 + wm * Cfg::WM + 32 * i, n0 + wn * Cfg::WN + 32 * j, lane);
+        stage_acc<Cfg, false>(acc, smem);
+        eqk.template run<Cfg>((const float *)smem, m0, n0);
     } else {
         gemm_mainloop<Cfg, true>(al, W, K, m0, n0, M, N, K, smem, acc);
-#pragma unroll
-        for (int i = 0; i < Cfg::TM; ++i)
-#pragma unroll
-            for (int j = 0; j < Cfg::TN; ++j) ev(acc[i][j], m0 + wm * Cfg::WM + 32 * i, n0 + wn * Cfg::WN + 32 * j, lane);
+        stage_acc<Cfg, true>(acc, smem);
+        ev.template run<Cfg>((const float *)smem, m0, n0);
     }
 }
 
@@ -183,6 +430,11 @@ static hipError_t launch_qkv_cfg(const RowLoader &al, const bf16 *w, int M, int 
 hipError_t launch_qkv(const bf16 *a, const bf16 *w, const float *bias, bf16 *q, bf16 *k, bf16 *vt, float *qkv_f32,
                       int batch, int n_tokens, int n_pad, int heads, hipStream_t s) {
     const int D = heads * 64, M = batch * n_tokens;
+    static const char *qkv_panel = getenv("OCM_QKV_PANEL");  // development switch (the panel qkv epilogue spills)
+    if (qkv_panel && panel_ok(M, 3 * D, D)) {
+        PanelEpiQKV pepi{bias, q, k, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
+        return launch_panel(a, w, M, 3 * D, D, pepi, s);
+    }
     RowLoader al{a, D};
     EpiQK eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
     EpiVt ev{bias, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
@@ -236,19 +488,18 @@ struct EpiPatch {
     const float *bias, *pos;
     float *x;
     int M, P, ntok, D;
-    __device__ __forceinline__ void operator()(const f32x16 &acc, int mb, int nb, int lane) const {
-        if (nb >= D || mb >= M) return;
-        const int n = nb + (lane & 31), h = lane >> 5;
-        const float bv = bias[n];
-        const int b0 = mb / P, t0 = mb - b0 * P;
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int dl = acc_row32(reg, h);
-            if (mb + dl < M) {
-                int t = t0 + dl, b = b0;
-                while (t >= P) { t -= P; ++b; }
-                x[((int64_t)b * ntok + 1 + t) * D + n] = acc[reg] + bv + pos[(int64_t)(1 + t) * D + n];
-            }
+    template <class Cfg>
+    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
+        constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, CPR = BN / 4;
+#pragma unroll 4
+        for (int q = threadIdx.x; q < BM * CPR; q += NT) {
+            const int row = q / CPR, col = (q - row * CPR) * 4;
+            const int m = m0 + row, n = n0 + col;
+            if (m >= M || n >= D) continue;
+            const int b = m / P, t = m - b * P;
+            const f32x4 v = *(const f32x4 *)(C + row * BN + col) + *(const f32x4 *)(bias + n) +
+                            *(const f32x4 *)(pos + (int64_t)(1 + t) * D + n);
+            *(f32x4 *)(x + ((int64_t)b * ntok + 1 + t) * D + n) = v;
         }
     }
 };
@@ -261,3 +512,10 @@ hipError_t launch_patch_embed(const PatchArgs &pa, const bf16 *w, const float *b
     if (dim % 128 == 0 && M > 64) return launch_gemm<Cfg64x128, false>(al, w, K, M, dim, K, epi, s);
     return launch_gemm<Cfg64x64, false>(al, w, K, M, dim, K, epi, s);
 }
+
+#ifdef PANEL_STAMP
+extern "C" int ocm_debug_panel_stamps(unsigned long long *out, int n) {
+    if (n > 512) n = 512;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif

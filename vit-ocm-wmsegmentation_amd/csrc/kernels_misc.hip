@@ -61,9 +61,78 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     }
 }
 
+// Fast path for dim % 128 == 0 (ViT-S 384, ViT-B 768): half a wavefront per row, float4 loads
+// (dim/128 per lane, all issued before the first use), 8-byte bf16 / 16-byte fp32 stores.
+template <bool OUT_BF16, int NV>
+__global__ __launch_bounds__(256) void layernorm_v4_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, void *__restrict__ y,
+                                                           int64_t rows, float eps) {
+    constexpr int dim = NV * 128;
+    const int sub = threadIdx.x & 31;
+    const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= rows) return;
+    const float *xr = x + row * dim;
+    f32x4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = *(const f32x4 *)(xr + sub * 4 + i * 128);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.0f / dim);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            q = fmaf(d, d, q);
+        }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / dim) + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = sub * 4 + i * 128;
+        const f32x4 g = *(const f32x4 *)(gamma + c), b = *(const f32x4 *)(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+        if (OUT_BF16) {
+            bf16x4 ob;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ob[e] = (bf16)o[e];
+            *(bf16x4 *)((bf16 *)y + row * dim + c) = ob;
+        } else {
+            *(f32x4 *)((float *)y + row * dim + c) = o;
+        }
+    }
+}
+
+template <int NV>
+static hipError_t launch_ln_v4(const float *x, const float *gamma, const float *beta, void *y, bool out_bf16,
+                               int64_t rows, float eps, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 7) / 8)), block(256);
+    if (out_bf16)
+        layernorm_v4_kernel<true, NV><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, eps);
+    else
+        layernorm_v4_kernel<false, NV><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, eps);
+    return hipGetLastError();
+}
+
 hipError_t launch_layernorm(const float *x, const float *gamma, const float *beta, void *y, bool out_bf16,
                             int64_t rows, int dim, float eps, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
+    switch (dim) {
+        case 128: return launch_ln_v4<1>(x, gamma, beta, y, out_bf16, rows, eps, s);
+        case 256: return launch_ln_v4<2>(x, gamma, beta, y, out_bf16, rows, eps, s);
+        case 384: return launch_ln_v4<3>(x, gamma, beta, y, out_bf16, rows, eps, s);
+        case 512: return launch_ln_v4<4>(x, gamma, beta, y, out_bf16, rows, eps, s);
+        case 768: return launch_ln_v4<6>(x, gamma, beta, y, out_bf16, rows, eps, s);
+        case 1024: return launch_ln_v4<8>(x, gamma, beta, y, out_bf16, rows, eps, s);
+        default: break;
+    }
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     if (out_bf16)
         layernorm_kernel<true><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, dim, eps);
