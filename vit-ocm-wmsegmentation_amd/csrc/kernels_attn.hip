@@ -24,6 +24,8 @@
 //
 // attn_rows_kernel — only selected query rows with the CLS column dropped (what
 //   compute_attention consumes): one wavefront per (row, b, h), fp32 dot products.
+#include <stdlib.h>
+
 #include "launch.h"
 
 #define LOG2E 1.4426950408889634f
@@ -193,8 +195,163 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
     }
 }
 
+// Whole-sequence variant for N <= 256 tokens (ViT-S/16 and ViT-B/16 at 224^2: N = 197): one workgroup
+// of 8 waves per (batch, head); ALL keys / values of that head are brought into LDS by one burst of
+// loads (K: 32 KiB as [256][64], V^T: 32 KiB as 4 blocks of [64 d][64 keys]) behind a single barrier,
+// then every wave walks the key tiles of its 32 query rows with no further synchronisation. Compared
+// with the streaming kernel this loads K/V once per head instead of once per 128 queries and removes
+// the per-tile load -> LDS -> barrier latency chain (4 exposed round trips at N = 197).
+template <bool WANT_O>
+__global__ __launch_bounds__(512, 4) void attn_small_kernel(const bf16 *__restrict__ Q, const bf16 *__restrict__ Kk,
+                                                            const bf16 *__restrict__ Vt, bf16 *__restrict__ ctx,
+                                                            float *__restrict__ lse2, int N, int npad, int H,
+                                                            float scale2) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 256 * 128];  // K | Vt, 32 KiB each
+    char *Ks = smem, *Vs = smem + 256 * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.x;
+    const int q0 = wave * 32;
+    const bf16 *Qb = Q + (int64_t)bh * npad * 64;
+    const bf16 *Kb = Kk + (int64_t)bh * npad * 64;
+    const bf16 *Vb = Vt + (int64_t)bh * 64 * npad;
+    const int ntiles = (N + 63) >> 6;
+
+    bf16x8 qf[4];
+    {
+        const int qrow = min(q0 + r, N - 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8 *)(Qb + (int64_t)qrow * 64 + 16 * s + 8 * h);
+    }
+    {
+        bf16x8 rk[4], rv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qd = tid + 512 * i, row = qd >> 3, c = qd & 7;  // K row (key), 16-B chunk
+            rk[i] = *(const bf16x8 *)(Kb + (int64_t)min(row, N - 1) * 64 + c * 8);
+            // V^T: block kb = i (64 keys), row d = (tid >> 3), chunk = 8 keys
+            const int d = tid >> 3, key0 = i * 64 + c * 8;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            if (key0 < npad) {
+                v = *(const bf16x8 *)(Vb + (int64_t)d * npad + key0);
+                if (key0 + 8 > N) {  // padding keys must be exact zeros: P = 0 times garbage may be NaN
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (key0 + e >= N) v[e] = (bf16)0.f;
+                }
+            }
+            rv[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qd = tid + 512 * i, row = qd >> 3, c = qd & 7;
+            *(bf16x8 *)(Ks + lds_off(row, c)) = rk[i];
+            *(bf16x8 *)(Vs + i * 8192 + lds_off(tid >> 3, c)) = rv[i];
+        }
+    }
+    lds_barrier();
+    if (q0 >= N) return;  // no barrier below
+
+    f32x16 O[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[0][e] = O[1][e] = 0.f;
+    float m = -INFINITY, l = 0.f;  // m is in the scaled (log2) domain
+    const int pr = pi_row(r);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const char *Kt = Ks + kt * 8192, *Vtile = Vs + kt * 8192;
+        f32x16 S[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[sub][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 a = *(const bf16x8 *)(Kt + sub * 32 * 128 + lds_off(pr, 2 * s + h));
+                S[sub] = mfma32(a, qf[s], S[sub]);
+            }
+        }
+        if ((kt + 1) * 64 > N) {  // tail tile: padding keys -> -inf (wave-uniform branch)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (kt * 64 + sub * 32 + key_of_reg(e, h) >= N) S[sub][e] = -INFINITY;
+        }
+        // max on the raw scores (scale > 0 commutes with max), scale folded into the exp2 argument
+        float mx = fmaxf(S[0][0], S[1][0]);
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(S[0][e], S[1][e]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx * scale2);
+        const float alpha = fast_exp2(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = fast_exp2(fmaf(S[sub][e], scale2, -mn));
+                S[sub][e] = p;
+                ps += p;
+            }
+        l = fmaf(l, alpha, ps);
+        if (WANT_O) {
+            if (__any(alpha != 1.0f)) {  // the running max moved somewhere in this wave
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    O[0][e] *= alpha;
+                    O[1][e] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 pb;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pb[e] = (bf16)S[sub][8 * s2 + e];
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const bf16x8 a = *(const bf16x8 *)(Vtile + db * 32 * 128 + lds_off(r, 4 * sub + 2 * s2 + h));
+                        O[db] = mfma32(a, pb, O[db]);
+                    }
+                }
+        }
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const int qrow = q0 + r;
+    if (qrow < N) {
+        if (lse2 && h == 0) lse2[(int64_t)bh * N + qrow] = m + __log2f(lt);
+        if (WANT_O) {
+            const float inv = 1.0f / lt;
+            const int b = bh / H, head = bh - b * H;
+            bf16 *dst = ctx + ((int64_t)b * N + qrow) * (H * 64) + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(O[db][4 * g + e] * inv);
+                    *(bf16x4 *)(dst + db * 32 + 8 * g + 4 * h) = o;
+                }
+        }
+    }
+}
+
 hipError_t launch_attention(const bf16 *q, const bf16 *k, const bf16 *vt, bf16 *ctx, float *lse2, int batch,
                             int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
+    static const char *force_stream = getenv("OCM_ATTN_STREAM");  // development switch
+    if (n_tokens <= 256 && !force_stream) {
+        const dim3 grid(batch * heads), block(512);
+        if (ctx)
+            attn_small_kernel<true><<<grid, block, 0, s>>>(q, k, vt, ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+        else
+            attn_small_kernel<false><<<grid, block, 0, s>>>(q, k, vt, ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+        return hipGetLastError();
+    }
     const int qtiles = (n_tokens + 31) / 32;
     const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
     if (ctx)
