@@ -41,10 +41,10 @@ struct RowLoader {
 
 // Main loop. acc[i][j] is the 32x32 tile at rows wm*WM+32i, cols wn*WN+32j of the block
 // tile; with SWAP the register/lane roles of that tile are transposed (lane = row m).
-template <class Cfg, bool SWAP, class ALoad>
+template <class Cfg, bool SWAP, int KSTEPS, class ALoad>
 __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const bf16 *__restrict__ W, int64_t ldw,
                                               int m0, int n0, int M, int N, int K, char *smem,
-                                              f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+                                              f32x16 (&acc)[Cfg::TM][Cfg::TN], const float *__restrict__ bias) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
     constexpr int A_CH = Cfg::A_CH, B_CH = Cfg::B_CH, TM = Cfg::TM, TN = Cfg::TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,13 +86,85 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const bf16 *__res
         for (int i = 0; i < B_CH; ++i) *(bf16x8 *)(Bs + buf * BN * 128 + b_off[i]) = rb[i];
     };
 
+    // Accumulators start at the bias (one load per column / register row, issued together with the
+    // first operand tile): the epilogues then add nothing and issue no dependent global loads.
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + wn * Cfg::WN + 32 * j;
+        if (!SWAP) {
+            const float bv = bias ? bias[min(nb + r, N - 1)] : 0.f;  // lane = output column
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = bv;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {  // registers = output column
+                const float bv = bias ? bias[min(nb + acc_row32(e, h), N - 1)] : 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i][j][e] = bv;
+            }
+        }
+    }
 
+    if constexpr (KSTEPS > 0 && KSTEPS % 2 == 0) {
+        // K known at compile time (KSTEPS 64-wide steps, even): two register staging slots give a
+        // prefetch distance of TWO steps — the tile committed to LDS in step t was requested in step
+        // t-2 (L2 latency under load is ~1 us, more than one step). The stream is unconditional
+        // (indices past the end re-read the last tile into a dead slot) and the trip count is a
+        // constant, so hipcc can count its own `s_waitcnt vmcnt(N)` instead of draining to 0.
+        struct Slot {
+            typename ALoad::Raw a[A_CH];
+            bf16x8 b[B_CH];
+        };
+        auto issue2 = [&](Slot &sl, int t) {
+            const int k0 = min(t, KSTEPS - 1) << 6;
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) sl.a[i] = al.load(a_h[i], k0 + a_k[i]);
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) sl.b[i] = *(const bf16x8 *)(b_h[i] + k0 + b_k[i]);
+        };
+        auto commit2 = [&](int buf, const Slot &sl) {
+#pragma unroll
+            for (int i = 0; i < A_CH; ++i) *(bf16x8 *)(As + buf * BM * 128 + a_off[i]) = ALoad::finish(sl.a[i]);
+#pragma unroll
+            for (int i = 0; i < B_CH; ++i) *(bf16x8 *)(Bs + buf * BN * 128 + b_off[i]) = sl.b[i];
+        };
+        auto compute = [&](int buf) {
+            const char *Ab = As + buf * BM * 128 + (wm * Cfg::WM) * 128;
+            const char *Bb = Bs + buf * BN * 128 + (wn * Cfg::WN) * 128;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                bf16x8 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8 *)(Ab + i * 32 * 128 + lds_off(r, 2 * s + h));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8 *)(Bb + j * 32 * 128 + lds_off(r, 2 * s + h));
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = SWAP ? mfma32(b[j], a[i], acc[i][j]) : mfma32(a[i], b[j], acc[i][j]);
+            }
+        };
+        Slot s0, s1;
+        issue2(s0, 0);
+        issue2(s1, 1);
+        commit2(0, s0);
+        issue2(s0, 2);  // s1 = tile 1, s0 = tile 2
+        lds_barrier();
+        for (int t = 0; t < KSTEPS; t += 2) {
+            compute(0);      // tile t (even tiles live in buffer 0)
+            commit2(1, s1);  // tile t+1
+            issue2(s1, t + 3);
+            lds_barrier();
+            compute(1);      // tile t+1
+            commit2(0, s0);  // tile t+2 (a dead duplicate after the last tile)
+            issue2(s0, t + 4);
+            lds_barrier();
+        }
+        return;
+    }
     const int nt = K >> 6;
     issue(0);
     commit(0);
@@ -155,7 +227,7 @@ __device__ __forceinline__ void stage_acc(const f32x16 (&acc)[Cfg::TM][Cfg::TN],
 
 // Generic kernel: grid = tiles_m * tiles_n workgroups (linear, XCD-remapped so the
 // workgroups that share an A row panel sit on one XCD's L2).
-template <class Cfg, bool SWAP, class ALoad, class Epi>
+template <class Cfg, bool SWAP, int KSTEPS, class ALoad, class Epi>
 __global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const bf16 *__restrict__ W, int64_t ldw,
                                                        int M, int N, int K, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -164,7 +236,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const bf16 *__r
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
-    gemm_mainloop<Cfg, SWAP>(al, W, ldw, m0, n0, M, N, K, smem, acc);
+    gemm_mainloop<Cfg, SWAP, KSTEPS>(al, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
     stage_acc<Cfg, SWAP>(acc, smem);
     epi.template run<Cfg>((const float *)smem, m0, n0);
 }

@@ -14,8 +14,10 @@
 // ------------------------------------------------------------------------------------------
 // nn.Linear epilogues
 // ------------------------------------------------------------------------------------------
-// out = epilogue(acc + bias). fp32 outputs move 16 B (4 columns) per lane, bf16 outputs 16 B
-// (8 columns) per lane; `resid` may alias `out` (each element is read then written by one lane).
+// out = epilogue(acc) with the bias already in the accumulator (gemm_mainloop). fp32 outputs move
+// 16 B (4 columns) per lane, bf16 outputs 16 B (8 columns) per lane. The residual of ALL of a lane's
+// chunks is requested in one burst before the first use (one exposed L2 round trip instead of one per
+// unrolled group); `resid` may alias `out` (each element is read then written by the same lane).
 template <int MODE>
 struct EpiLinear {
     const float *bias;
@@ -29,16 +31,27 @@ struct EpiLinear {
         constexpr bool OUT_BF16 = (MODE == 2 || MODE == 3);
         constexpr int W = OUT_BF16 ? 8 : 4;  // columns per lane
         constexpr int CPR = BN / W;          // chunks per row
-#pragma unroll 4
-        for (int q = threadIdx.x; q < BM * CPR; q += NT) {
-            const int row = q / CPR, col = (q - row * CPR) * W;
-            const int m = m0 + row, n = n0 + col;
-            if (m >= M || n >= N) continue;
+        constexpr int ITERS = BM * CPR / NT;
+        static_assert(NT % CPR == 0, "a lane keeps one column chunk");
+        const int col = (threadIdx.x % CPR) * W, row0 = threadIdx.x / CPR;
+        const int n = n0 + col;
+        if (n >= N) return;
+        f32x4 rs[MODE == 1 ? ITERS : 1];
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < ITERS; ++i) {
+                const int m = min(m0 + row0 + i * (NT / CPR), M - 1);
+                rs[i] = *(const f32x4 *)(resid + (int64_t)m * ldo + n);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < ITERS; ++i) {
+            const int row = row0 + i * (NT / CPR), m = m0 + row;
+            if (m >= M) continue;
             const int64_t o = (int64_t)m * ldo + n;
             f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
-            if (bias) v0 += *(const f32x4 *)(bias + n);
             if (!OUT_BF16) {
-                if (MODE == 1) v0 += *(const f32x4 *)(resid + o);
+                if (MODE == 1) v0 += rs[i];
                 if (MODE == 100) {
                     if (v0[0] == 123456.789f) *(f32x4 *)((float *)out + o) = v0;  // experiment: main loop only
                 } else {
@@ -46,7 +59,6 @@ struct EpiLinear {
                 }
             } else {
                 f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4);
-                if (bias) v1 += *(const f32x4 *)(bias + n + 4);
                 if (MODE == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
@@ -61,10 +73,10 @@ struct EpiLinear {
     }
 };
 
-template <class Cfg, bool SWAP, class ALoad, class Epi>
-static hipError_t launch_gemm(const ALoad &al, const bf16 *w, int64_t ldw, int M, int N, int K, const Epi &epi,
-                              hipStream_t s) {
-    auto kern = gemm_kernel<Cfg, SWAP, ALoad, Epi>;
+template <class Cfg, bool SWAP, int KSTEPS, class ALoad, class Epi>
+static hipError_t launch_gemm_ks(const ALoad &al, const bf16 *w, int64_t ldw, int M, int N, int K, const Epi &epi,
+                                 hipStream_t s) {
+    auto kern = gemm_kernel<Cfg, SWAP, KSTEPS, ALoad, Epi>;
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -75,6 +87,22 @@ static hipError_t launch_gemm(const ALoad &al, const bf16 *w, int64_t ldw, int M
     const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
     kern<<<dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, s>>>(al, w, ldw, M, N, K, epi);
     return hipGetLastError();
+}
+
+// The K extents of ViT-S/B (D and 4D, and the patch embedding) get a compile-time step count, which
+// unlocks the two-step prefetch of gemm_mainloop; any other K runs the generic one-step pipeline.
+template <class Cfg, bool SWAP, class ALoad, class Epi>
+static hipError_t launch_gemm(const ALoad &al, const bf16 *w, int64_t ldw, int M, int N, int K, const Epi &epi,
+                              hipStream_t s) {
+    static const char *generic = getenv("OCM_GEMM_GENERIC");  // development switch
+    if (!generic) switch (K) {
+        case 384: return launch_gemm_ks<Cfg, SWAP, 6>(al, w, ldw, M, N, K, epi, s);
+        case 768: return launch_gemm_ks<Cfg, SWAP, 12>(al, w, ldw, M, N, K, epi, s);
+        case 1536: return launch_gemm_ks<Cfg, SWAP, 24>(al, w, ldw, M, N, K, epi, s);
+        case 3072: return launch_gemm_ks<Cfg, SWAP, 48>(al, w, ldw, M, N, K, epi, s);
+        default: break;
+    }
+    return launch_gemm_ks<Cfg, SWAP, 0>(al, w, ldw, M, N, K, epi, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -352,8 +380,8 @@ struct EpiQK {
             if (m >= M) continue;
             const int which = n / D, rem = n - which * D, head = rem >> 6, d = rem & 63;
             const int b = m / ntok, t = m - b * ntok;
-            const f32x4 v0 = *(const f32x4 *)(C + row * BN + col) + *(const f32x4 *)(bias + n);
-            const f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4) + *(const f32x4 *)(bias + n + 4);
+            const f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
+            const f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4);
             bf16 *dst = which ? k : q;
             *(bf16x8 *)(dst + ((int64_t)(b * H + head) * npad + t) * 64 + d) = cvt8(v0, v1);
             if (qkv32) {
@@ -383,14 +411,14 @@ struct EpiVt {
 #pragma unroll 4
         for (int row = threadIdx.x / BM; row < BN; row += NT / BM) {
             const int rem = rem0 + row, head = rem >> 6, d = rem & 63;
-            const float v = C[row * BM + col] + bias[n0 + row];
+            const float v = C[row * BM + col];
             vt[((int64_t)(b * H + head) * 64 + d) * npad + t] = (bf16)v;
             if (qkv32) qkv32[((((int64_t)2 * B + b) * H + head) * ntok + t) * 64 + d] = v;
         }
     }
 };
 
-template <class Cfg>
+template <class Cfg, int KSTEPS>
 __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader al, const bf16 *__restrict__ W, int M, int D,
                                                       EpiQK eqk, EpiVt ev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -401,20 +429,20 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader al, const bf16 *
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
     if (n0 < 2 * D) {  // workgroup-uniform
-        gemm_mainloop<Cfg, false>(al, W, K, m0, n0, M, N, K, smem, acc);
+        gemm_mainloop<Cfg, false, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
         stage_acc<Cfg, false>(acc, smem);
         eqk.template run<Cfg>((const float *)smem, m0, n0);
     } else {
-        gemm_mainloop<Cfg, true>(al, W, K, m0, n0, M, N, K, smem, acc);
+        gemm_mainloop<Cfg, true, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
         stage_acc<Cfg, true>(acc, smem);
         ev.template run<Cfg>((const float *)smem, m0, n0);
     }
 }
 
-template <class Cfg>
-static hipError_t launch_qkv_cfg(const RowLoader &al, const bf16 *w, int M, int D, const EpiQK &eqk, const EpiVt &ev,
-                                 hipStream_t s) {
-    auto kern = qkv_kernel<Cfg>;
+template <class Cfg, int KSTEPS>
+static hipError_t launch_qkv_ks(const RowLoader &al, const bf16 *w, int M, int D, const EpiQK &eqk, const EpiVt &ev,
+                                hipStream_t s) {
+    auto kern = qkv_kernel<Cfg, KSTEPS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -425,6 +453,15 @@ static hipError_t launch_qkv_cfg(const RowLoader &al, const bf16 *w, int M, int 
     const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * (3 * D / Cfg::BN);
     kern<<<dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, s>>>(al, w, M, D, eqk, ev);
     return hipGetLastError();
+}
+
+template <class Cfg>
+static hipError_t launch_qkv_cfg(const RowLoader &al, const bf16 *w, int M, int D, const EpiQK &eqk, const EpiVt &ev,
+                                 hipStream_t s) {
+    static const char *generic = getenv("OCM_GEMM_GENERIC");
+    if (!generic && D == 384) return launch_qkv_ks<Cfg, 6>(al, w, M, D, eqk, ev, s);
+    if (!generic && D == 768) return launch_qkv_ks<Cfg, 12>(al, w, M, D, eqk, ev, s);
+    return launch_qkv_ks<Cfg, 0>(al, w, M, D, eqk, ev, s);
 }
 
 hipError_t launch_qkv(const bf16 *a, const bf16 *w, const float *bias, bf16 *q, bf16 *k, bf16 *vt, float *qkv_f32,
@@ -497,8 +534,7 @@ struct EpiPatch {
             const int m = m0 + row, n = n0 + col;
             if (m >= M || n >= D) continue;
             const int b = m / P, t = m - b * P;
-            const f32x4 v = *(const f32x4 *)(C + row * BN + col) + *(const f32x4 *)(bias + n) +
-                            *(const f32x4 *)(pos + (int64_t)(1 + t) * D + n);
+            const f32x4 v = *(const f32x4 *)(C + row * BN + col) + *(const f32x4 *)(pos + (int64_t)(1 + t) * D + n);
             *(f32x4 *)(x + ((int64_t)b * ntok + 1 + t) * D + n) = v;
         }
     }
