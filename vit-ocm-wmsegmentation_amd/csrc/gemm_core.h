@@ -171,9 +171,7 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const bf16 *__res
     lds_barrier();
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
-#if !defined(TILE_EXP) || TILE_EXP != 6
         if (t + 1 < nt) issue((t + 1) << 6);
-#endif
         const char *Ab = As + buf * BM * 128 + (wm * Cfg::WM) * 128;
         const char *Bb = Bs + buf * BN * 128 + (wn * Cfg::WN) * 128;
 #pragma unroll
@@ -189,9 +187,6 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const bf16 *__res
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-#if defined(TILE_EXP) && TILE_EXP == 5
-                    if (i + j + s == 0)
-#endif
                     acc[i][j] = SWAP ? mfma32(b[j], a[i], acc[i][j]) : mfma32(a[i], b[j], acc[i][j]);
         }
         if (t + 1 < nt) commit(buf ^ 1);
