@@ -110,11 +110,20 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU (RCCL). OCM_BENCH_BACKEND=gloo lets the N>1 code path be rehearsed on a 1-GPU box
+    # (ranks share device 0, the all-gather goes through gloo); it is never the measured configuration.
+    backend = os.environ.get("OCM_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        sys.exit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} HIP device(s) visible")
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import vit_ocm_wmsegmentation_amd.dino.vision_transformer as vits
     from vit_ocm_wmsegmentation_amd import _lib, synth
