@@ -28,6 +28,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_FP32_MFMA_TFLOPS = 157.3    # same guide: f32-input MFMA = 1/16 of the bf16 rate
 
 
 def flops_per_tile(D, L, p, S, in_chans=3):
@@ -98,6 +99,8 @@ def main():
     ap.add_argument("--arch", default="vit_small")
     ap.add_argument("--patch", type=int, default=16)
     ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
+                    help="operand precision of the contraction kernels (default: BASELINE.json's bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-class table to stderr")
     args = ap.parse_args()
@@ -135,7 +138,7 @@ def main():
     model.load_state_dict(synth.synth_arch_state_dict(args.arch, p, seed=0, variant="init"))
     for q in model.parameters():
         q.requires_grad = False
-    model.eval().to(dev)
+    model.eval().to(dev).set_precision(args.precision)
     x = synth.synth_tiles(B, S, seed=1234 + rank).to(dev)  # resident in HBM before timing
     fmap, N = flops_per_tile(D, L, p, S)
 
@@ -231,7 +234,7 @@ def main():
     # HBM bytes per launch of the dominant class: measured offline with rocprofv3 --pmc (separate passes,
     # gfx950 FETCH_SIZE correction) and committed under profiles/; only valid for the default workload
     traffic = None
-    if (args.arch, p, S, B) == ("vit_small", 16, 224, 64):
+    if (args.arch, p, S, B, args.precision) == ("vit_small", 16, 224, 64, "bf16"):
         try:
             traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[dom]["traffic_bytes"]
         except (OSError, KeyError, ValueError):
@@ -240,6 +243,7 @@ def main():
     value = tiles / dt
     dom_avg_s = dom_ms / max(dom_n, 1) * 1e-3
     achieved = cf[dom] / dom_avg_s / 1e12 if dom_n else None
+    peak = PEAK_BF16_DENSE_TFLOPS if args.precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
     line = {
         "metric": "OCM tiles/s (224x224, ViT-S/16 attention-map inference)" if (args.arch, p, S) == ("vit_small", 16, 224)
         else f"OCM tiles/s ({S}x{S}, {args.arch}/{p} attention-map inference)",
@@ -252,17 +256,17 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16",
+        "dtype": "bf16" if args.precision == "bf16" else "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.arch} patch {p}, {B} tiles/GPU of {S}x{S} (RGB-replicated grayscale), "
                                f"get_last_selfattention -> (B,{H},{N},{N}) fp32 + CLS-row maps; random-init weights",
                    "tiles_per_gpu": B, "tokens": N, "parallelism": f"tile-shard x{world}" + (" + all-gather" if world > 1 else "")},
         "attn_linf_vs_cpu_oracle": linf,
         "path_tflops": round(value * fmap / 1e12, 2),
-        "path_frac_of_bf16_peak": round(value * fmap / 1e12 / (PEAK_BF16_DENSE_TFLOPS * world), 4),
+        "path_frac_of_mfma_peak": round(value * fmap / 1e12 / (peak * world), 4),
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2) if achieved else None,
-                     "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_BF16_DENSE_TFLOPS, 4) if achieved else None,
+                     "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(achieved / peak, 4) if achieved else None,
                      "traffic": traffic, "launches": int(dom_n), "avg_launch_us": round(dom_avg_s * 1e6, 2),
                      "flop_per_launch": cf[dom]},
         "kernel_breakdown": breakdown,

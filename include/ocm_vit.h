@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCM_ABI_VERSION 1
+#define OCM_ABI_VERSION 2
 
 enum {
     OCM_OK = 0,
@@ -43,8 +43,9 @@ enum {
 /* Arithmetic of the contraction kernels. The residual stream, LayerNorm
  * statistics, softmax and all accumulators are fp32 in every mode. */
 enum {
-    OCM_PREC_BF16 = 0,   /* bf16 MFMA operands, fp32 accumulate                        */
-    OCM_PREC_BF16X3 = 1  /* split-bf16 (hi+lo) operands, 3 MFMAs per product (~fp32)   */
+    OCM_PREC_BF16 = 0, /* bf16 operands, v_mfma_f32_32x32x16_bf16, fp32 accumulate (fast path)            */
+    OCM_PREC_FP32 = 1  /* fp32 operands, v_mfma_f32_32x32x2_f32: exact fp32 products, 1/16 the MFMA rate;
+                          matrices, activations, q/k/v and P stay fp32 end to end (reference-grade maps) */
 };
 
 /* Hyper-parameters: VisionTransformer.__init__ (vision_transformer.py:137-165) and
@@ -170,35 +171,38 @@ enum {
     OCM_EPI_BIAS_GELU_BF16 = 2, /* out bf16 [M][N] = gelu_erf(acc + bias) (fc1 + act :58-59)     */
     OCM_EPI_BIAS_BF16 = 3       /* out bf16 [M][N] = acc + bias                                  */
 };
-/* nn.Linear: out = epilogue(A[M][K] · W[N][K]^T + bias[N]); A, W bf16 row-major,
+/* The stand-alone contraction operators take `precision` (OCM_PREC_*): operand / activation buffers
+ * named E are bf16 for OCM_PREC_BF16 and fp32 for OCM_PREC_FP32 (the *_BF16 epilogues then emit E). */
+
+/* nn.Linear: out = epilogue(A[M][K] · W[N][K]^T + bias[N]); A, W of type E row-major,
  * K % 64 == 0, N % 32 == 0. resid may alias out. */
-int ocm_op_linear(const void *a_bf16, const void *w_bf16, const float *bias, const float *resid,
+int ocm_op_linear(int32_t precision, const void *a, const void *w, const float *bias, const float *resid,
                   void *out, int32_t M, int32_t N, int32_t K, int32_t epilogue, void *stream);
 
 /* Head-major packed projections the attention kernels consume:
- *   q, k : bf16 [B*H][n_pad][64];  vt : bf16 [B*H][64][n_pad],  n_pad = ocm_n_pad(N). */
+ *   q, k : E [B*H][n_pad][64];  vt : E [B*H][64][n_pad],  n_pad = ocm_n_pad(N). */
 int32_t ocm_n_pad(int32_t n_tokens);
 
 /* Attention.forward qkv projection (:80): A[B*N][D] bf16 · Wqkv[3D][D]^T + b -> q/k/vt
  * (and, when qkv_f32 != NULL, the fp32 (3,B,H,N,64) tensor the reference returns). */
-int ocm_op_qkv_proj(const void *a_bf16, const void *w_bf16, const float *bias, void *q, void *k,
+int ocm_op_qkv_proj(int32_t precision, const void *a, const void *w, const float *bias, void *q, void *k,
                     void *vt, float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads,
                     void *stream);
 
-/* softmax(q k^T * scale) v (:83-87). ctx bf16 [B][N][H*64] (or NULL);
+/* softmax(q k^T * scale) v (:83-87). ctx E [B][N][H*64] (or NULL);
  * lse2 fp32 [B*H][N] = log2-domain log-sum-exp of the scaled scores (or NULL). */
-int ocm_op_attention(const void *q, const void *k, const void *vt, void *ctx_bf16, float *lse2,
+int ocm_op_attention(int32_t precision, const void *q, const void *k, const void *vt, void *ctx, float *lse2,
                      int32_t batch, int32_t n_tokens, int32_t heads, float scale, void *stream);
 
 /* Attention probabilities (:83-84) from q, k and lse2: attn fp32 [B][H][N][N]. */
-int ocm_op_attention_probs(const void *q, const void *k, const float *lse2, float *attn,
+int ocm_op_attention_probs(int32_t precision, const void *q, const void *k, const float *lse2, float *attn,
                            int32_t batch, int32_t n_tokens, int32_t heads, float scale,
                            void *stream);
 
 /* Selected rows of the probabilities with the CLS column dropped
  * (utils.py:232, attentions[0, :, query, 1:]): rows fp32 [B][H][n_rows][N-1]. */
-int ocm_op_attention_rows(const void *q, const void *k, const int32_t *query_rows, int32_t n_rows,
-                          float *rows, int32_t batch, int32_t n_tokens, int32_t heads, float scale,
+int ocm_op_attention_rows(int32_t precision, const void *q, const void *k, const int32_t *query_rows,
+                          int32_t n_rows, float *rows, int32_t batch, int32_t n_tokens, int32_t heads, float scale,
                           void *stream);
 
 /* compute_attention (utils.py:229-235) on device: attn fp32 [B][H][N][N] ->

@@ -38,7 +38,7 @@ def test_create_rejects_bad_configs(lib):
         return lib.ocm_vit_create(C.byref(cfg), C.byref(h))
 
     for bad in (dict(embed_dim=100), dict(num_heads=5), dict(patch_size=7), dict(in_chans=2), dict(depth=0),
-                dict(mlp_hidden=100), dict(precision=7)):
+                dict(mlp_hidden=100), dict(precision=7), dict(precision=2)):
         assert create(**bad) == _lib.OCM_EINVAL, bad
         assert lib.ocm_last_error()
     with pytest.raises(ValueError):
@@ -46,12 +46,13 @@ def test_create_rejects_bad_configs(lib):
 
 
 def test_ops_validate_arguments(lib):
-    assert lib.ocm_op_linear(None, None, None, None, None, 1, 32, 64, 0, None) == _lib.OCM_EINVAL
+    assert lib.ocm_op_linear(0, None, None, None, None, None, 1, 32, 64, 0, None) == _lib.OCM_EINVAL
     one = C.c_void_p(256)
-    assert lib.ocm_op_linear(one, one, None, None, one, 10, 33, 64, 0, None) == _lib.OCM_EINVAL  # N % 32
-    assert lib.ocm_op_linear(one, one, None, None, one, 10, 32, 60, 0, None) == _lib.OCM_EINVAL  # K % 64
-    assert lib.ocm_op_linear(one, one, None, None, one, 10, 32, 64, 1, None) == _lib.OCM_EINVAL  # resid missing
-    assert lib.ocm_op_attention(one, one, one, None, None, 1, 10, 1, 0.125, None) == _lib.OCM_EINVAL
+    assert lib.ocm_op_linear(0, one, one, None, None, one, 10, 33, 64, 0, None) == _lib.OCM_EINVAL  # N % 32
+    assert lib.ocm_op_linear(0, one, one, None, None, one, 10, 32, 60, 0, None) == _lib.OCM_EINVAL  # K % 64
+    assert lib.ocm_op_linear(0, one, one, None, None, one, 10, 32, 64, 1, None) == _lib.OCM_EINVAL  # resid missing
+    assert lib.ocm_op_linear(7, one, one, None, None, one, 10, 32, 64, 0, None) == _lib.OCM_EINVAL  # precision
+    assert lib.ocm_op_attention(0, one, one, one, None, None, 1, 10, 1, 0.125, None) == _lib.OCM_EINVAL
     assert lib.ocm_op_attention_map(one, one, 0, 3, 10, 0, 2, 2, 8, None) == _lib.OCM_EINVAL  # hf*wf+1 != N
 
 

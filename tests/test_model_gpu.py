@@ -81,6 +81,29 @@ def test_golden_parity(dev, name):
             assert _rel(tokens.cpu(), gold[pfx + "tokens"]) < 5e-3
 
 
+@pytest.mark.parametrize("name", list(CASES))
+def test_golden_parity_fp32_mode(dev, name):
+    """OCM_PREC_FP32 (exact-fp32 MFMA, fp32 operands end to end): every golden case — the "peaked" stress
+    set included — inside the north star's 1e-3, in fact at fp32 round-off level."""
+    case, gold = CASES[name], load_golden(name)
+    model = build_module(case, dev).set_precision("fp32")
+    for idx, x in enumerate(case_inputs(case)):
+        pfx = f"in{idx}_"
+        feat, attns, qkvs = model.get_intermediate_feat(x.to(dev), case["n"])
+        a = attns[-1]
+        N = a.shape[-1]
+        e_cls = np.abs(a[:, :, 0, 1:].cpu().numpy() - gold[pfx + "cls_rows"]).max()
+        e_mid = np.abs(a[:, :, N // 2, :].cpu().numpy() - gold[pfx + "mid_rows"]).max()
+        r_feat = _rel(feat[-1][:, :4, :16].cpu(), gold[pfx + "feat_head"])
+        r_qkv = _rel(qkvs[-1][:, :, :, :3, :8].cpu(), gold[pfx + "qkv_head"])
+        print(f"\n[fp32 {name}/{idx}] attn L_inf: cls-row {e_cls:.2e} mid-row {e_mid:.2e}; feat rel {r_feat:.2e} qkv rel {r_qkv:.2e}")
+        assert e_cls <= 2e-5 and e_mid <= 2e-5
+        assert np.array_equal(a[:, :, 0, 1:].mean(1).argmax(-1).cpu().numpy(), gold[pfx + "argmax"]) or "init" in name \
+            or "full" in name  # near-uniform maps may tie; the peaked / sharp maxima must match exactly
+        assert r_feat < 2e-4 and r_qkv < 2e-4
+        assert torch.equal(model.get_last_selfattention(x.to(dev)), a)
+
+
 @pytest.mark.parametrize("name", ["tiny_p8", "vits16_sharp", "vits16_peaked"])
 def test_entry_points_agree_with_oracle(dev, name):
     """Every method of the module surface against the oracle on the same inputs (full tensors)."""

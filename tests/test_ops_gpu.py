@@ -67,7 +67,7 @@ def test_linear(lib, dev, M, N, K, epi):
     out = torch.full((M, N), float("nan"), dtype=torch.bfloat16 if out_bf16 else torch.float32, device=dev)
     if epi == 1:
         out.copy_(resid)  # in-place residual, as the engine uses it
-    _ok(lib, lib.ocm_op_linear(_p(a), _p(w), _p(bias), _p(out) if epi == 1 else None, _p(out), M, N, K, epi, _s()))
+    _ok(lib, lib.ocm_op_linear(0, _p(a), _p(w), _p(bias), _p(out) if epi == 1 else None, _p(out), M, N, K, epi, _s()))
     err = (out.float() - ref).abs()
     if out_bf16:
         assert (err <= ref.abs() * 2 ** -8 + 2e-4).all(), err.max().item()
@@ -93,7 +93,7 @@ def test_qkv_proj(lib, dev, B, N, H):
     k = torch.zeros_like(q)
     vt = torch.zeros((B * H, 64, npad), dtype=torch.bfloat16, device=dev)
     qkv32 = torch.empty((3, B, H, N, 64), dtype=torch.float32, device=dev)
-    _ok(lib, lib.ocm_op_qkv_proj(_p(a), _p(w), _p(bias), _p(q), _p(k), _p(vt), _p(qkv32), B, N, H, _s()))
+    _ok(lib, lib.ocm_op_qkv_proj(0, _p(a), _p(w), _p(bias), _p(q), _p(k), _p(vt), _p(qkv32), B, N, H, _s()))
     # reference: Attention.forward :80
     ref = (a.float() @ w.float().t() + bias).reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     assert (qkv32 - ref).abs().max().item() < 2e-4
@@ -138,24 +138,24 @@ def test_attention(lib, dev, B, N, H, sharp):
     oref = (pref @ v.float()).reshape(B, H, N, 64).permute(0, 2, 1, 3).reshape(B, N, H * 64)
     ctx = torch.full((B, N, H * 64), float("nan"), dtype=torch.bfloat16, device=dev)
     lse = torch.empty((B * H, N), dtype=torch.float32, device=dev)
-    _ok(lib, lib.ocm_op_attention(_p(qp), _p(kp), _p(vp), _p(ctx), _p(lse), B, N, H, scale, _s()))
+    _ok(lib, lib.ocm_op_attention(0, _p(qp), _p(kp), _p(vp), _p(ctx), _p(lse), B, N, H, scale, _s()))
     lse_ref = torch.logsumexp(s, -1) / math.log(2.0)
     assert (lse - lse_ref).abs().max().item() < 2e-4
     # P is rounded to bf16 before P·V and the output is bf16: ~2^-8 relative of |v|max-scaled rows
     assert (ctx.float() - oref).abs().max().item() < 0.03
     # probabilities from lse
     attn = torch.full((B, H, N, N), float("nan"), dtype=torch.float32, device=dev)
-    _ok(lib, lib.ocm_op_attention_probs(_p(qp), _p(kp), _p(lse), _p(attn), B, N, H, scale, _s()))
+    _ok(lib, lib.ocm_op_attention_probs(0, _p(qp), _p(kp), _p(lse), _p(attn), B, N, H, scale, _s()))
     assert (attn.reshape(B * H, N, N) - pref).abs().max().item() < 2e-5
     assert (attn.sum(-1) - 1).abs().max().item() < 1e-4
     # stats-only variant (no ctx) gives the same lse
     lse2 = torch.empty_like(lse)
-    _ok(lib, lib.ocm_op_attention(_p(qp), _p(kp), _p(vp), None, _p(lse2), B, N, H, scale, _s()))
+    _ok(lib, lib.ocm_op_attention(0, _p(qp), _p(kp), _p(vp), None, _p(lse2), B, N, H, scale, _s()))
     assert torch.equal(lse, lse2)
     # selected rows, CLS column dropped (utils.py:232)
     rows_idx = torch.tensor([0, N - 1, N // 2], dtype=torch.int32, device=dev)
     rows = torch.empty((B, H, 3, N - 1), dtype=torch.float32, device=dev)
-    _ok(lib, lib.ocm_op_attention_rows(_p(qp), _p(kp), _p(rows_idx), 3, _p(rows), B, N, H, scale, _s()))
+    _ok(lib, lib.ocm_op_attention_rows(0, _p(qp), _p(kp), _p(rows_idx), 3, _p(rows), B, N, H, scale, _s()))
     ref_rows = pref.reshape(B, H, N, N)[:, :, rows_idx.long(), 1:]
     assert (rows - ref_rows).abs().max().item() < 2e-5
 
@@ -171,3 +171,74 @@ def test_attention_map(lib, dev):
         ref = attn[b, :, query, 1:].reshape(H, hf, wf)
         ref = F.interpolate(ref.unsqueeze(0), scale_factor=p, mode="nearest")[0]
         assert torch.equal(maps, ref)  # pure index math: bit-exact
+
+
+# ---------------------------------------------------------------------------------------------
+# OCM_PREC_FP32: the same operators on fp32 operands (v_mfma_f32_32x32x2_f32 = exact fp32 products):
+# results must agree with a float64 reference to fp32 round-off.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (333, 384, 1536), (70, 96, 192), (64, 192, 64)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_linear_fp32(lib, dev, M, N, K, epi):
+    a = _rand((M, K), dev, 40)
+    w = _rand((N, K), dev, 41, 0.05)
+    bias = _rand((N,), dev, 42, 0.1)
+    resid = _rand((M, N), dev, 43)
+    ref = a.double() @ w.double().t() + bias.double()
+    if epi == 1:
+        ref = ref + resid.double()
+    if epi == 2:
+        ref = F.gelu(ref)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+    if epi == 1:
+        out.copy_(resid)
+    _ok(lib, lib.ocm_op_linear(1, _p(a), _p(w), _p(bias), _p(out) if epi == 1 else None, _p(out), M, N, K, epi, _s()))
+    assert (out.double() - ref).abs().max().item() < 2e-5 * max(1.0, math.sqrt(K) / 8)
+
+
+@pytest.mark.parametrize("B,N,H", [(3, 197, 6), (2, 17, 2), (5, 50, 3)])
+def test_qkv_proj_fp32(lib, dev, B, N, H):
+    D = H * 64
+    a, w, bias = _rand((B * N, D), dev, 50), _rand((3 * D, D), dev, 51, 0.05), _rand((3 * D,), dev, 52, 0.1)
+    npad = lib.ocm_n_pad(N)
+    q = torch.zeros((B * H, npad, 64), device=dev)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((B * H, 64, npad), device=dev)
+    qkv32 = torch.empty((3, B, H, N, 64), device=dev)
+    _ok(lib, lib.ocm_op_qkv_proj(1, _p(a), _p(w), _p(bias), _p(q), _p(k), _p(vt), _p(qkv32), B, N, H, _s()))
+    ref = (a.double() @ w.double().t() + bias.double()).reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    assert (qkv32.double() - ref).abs().max().item() < 2e-5
+    assert (q[:, :N].double() - ref[0].reshape(B * H, N, 64)).abs().max().item() < 2e-5
+    assert (k[:, :N].double() - ref[1].reshape(B * H, N, 64)).abs().max().item() < 2e-5
+    assert (vt[:, :, :N].double() - ref[2].reshape(B * H, N, 64).transpose(1, 2)).abs().max().item() < 2e-5
+    assert (q[:, N:] == 0).all() and (vt[:, :, N:] == 0).all()
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (1, 17, 2), (1, 577, 3), (1, 65, 1)])
+@pytest.mark.parametrize("sharp", [1.0, 3.0])
+def test_attention_fp32(lib, dev, B, N, H, sharp):
+    g = torch.Generator().manual_seed(60)
+    q = (torch.randn((B * H, N, 64), generator=g) * sharp).to(dev)
+    k = (torch.randn((B * H, N, 64), generator=g) * sharp).to(dev)
+    v = torch.randn((B * H, N, 64), generator=g).to(dev)
+    npad = lib.ocm_n_pad(N)
+    qp = torch.full((B * H, npad, 64), float("nan"), device=dev)
+    kp = torch.full((B * H, npad, 64), float("nan"), device=dev)
+    vp = torch.full((B * H, 64, npad), float("nan"), device=dev)
+    qp[:, :N], kp[:, :N], vp[:, :, :N] = q, k, v.transpose(1, 2)
+    scale = 0.125
+    s = (q.double() @ k.double().transpose(1, 2)) * scale
+    pref = s.softmax(-1)
+    oref = (pref @ v.double()).reshape(B, H, N, 64).permute(0, 2, 1, 3).reshape(B, N, H * 64)
+    ctx = torch.full((B, N, H * 64), float("nan"), device=dev)
+    lse = torch.empty((B * H, N), device=dev)
+    _ok(lib, lib.ocm_op_attention(1, _p(qp), _p(kp), _p(vp), _p(ctx), _p(lse), B, N, H, scale, _s()))
+    assert (lse.double() - torch.logsumexp(s, -1) / math.log(2.0)).abs().max().item() < 1e-4
+    assert (ctx.double() - oref).abs().max().item() < 2e-5
+    attn = torch.full((B, H, N, N), float("nan"), device=dev)
+    _ok(lib, lib.ocm_op_attention_probs(1, _p(qp), _p(kp), _p(lse), _p(attn), B, N, H, scale, _s()))
+    assert (attn.reshape(B * H, N, N).double() - pref).abs().max().item() < 2e-5
+    rows_idx = torch.tensor([0, N - 1], dtype=torch.int32, device=dev)
+    rows = torch.empty((B, H, 2, N - 1), device=dev)
+    _ok(lib, lib.ocm_op_attention_rows(1, _p(qp), _p(kp), _p(rows_idx), 2, _p(rows), B, N, H, scale, _s()))
+    assert (rows.double() - pref.reshape(B, H, N, N)[:, :, rows_idx.long(), 1:]).abs().max().item() < 2e-5

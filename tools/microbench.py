@@ -75,25 +75,21 @@ def main():
     tests = {
         "layernorm": (lambda: lib.ocm_op_layernorm(p(x32), p(gam), p(bet), p(xn_out), 1, T, D, 1e-6, s()), 0,
                       T * D * 6),
-        "qkv": (lambda: lib.ocm_op_qkv_proj(p(xn), p(w_qkv), p(b_qkv), p(q), p(k), p(vt), None, B, N, H, s()),
+        "qkv": (lambda: lib.ocm_op_qkv_proj(0, p(xn), p(w_qkv), p(b_qkv), p(q), p(k), p(vt), None, B, N, H, s()),
                 2.0 * T * D * 3 * D, 0),
-        "attention": (lambda: lib.ocm_op_attention(p(q), p(k), p(vt), p(ctx), None, B, N, H, 0.125, s()),
+        "attention": (lambda: lib.ocm_op_attention(0, p(q), p(k), p(vt), p(ctx), None, B, N, H, 0.125, s()),
                       4.0 * B * N * N * D, 0),
-        "attention_lse": (lambda: lib.ocm_op_attention(p(q), p(k), p(vt), None, p(lse), B, N, H, 0.125, s()),
+        "attention_lse": (lambda: lib.ocm_op_attention(0, p(q), p(k), p(vt), None, p(lse), B, N, H, 0.125, s()),
                           2.0 * B * N * N * D, 0),
-        "probs": (lambda: lib.ocm_op_attention_probs(p(q), p(k), p(lse), p(attn), B, N, H, 0.125, s()),
+        "probs": (lambda: lib.ocm_op_attention_probs(0, p(q), p(k), p(lse), p(attn), B, N, H, 0.125, s()),
                   2.0 * B * N * N * D, B * H * N * N * 4),
-        "proj": (lambda: lib.ocm_op_linear(p(xn), p(w_proj), p(b_d), p(x32), p(x32), T, D, D, 1, s()), 2.0 * T * D * D,
+        "proj": (lambda: lib.ocm_op_linear(0, p(xn), p(w_proj), p(b_d), p(x32), p(x32), T, D, D, 1, s()), 2.0 * T * D * D,
                  T * D * 10),
-        "fc1": (lambda: lib.ocm_op_linear(p(xn), p(w_fc1), p(b_m), None, p(out_h), T, M, D, 2, s()), 2.0 * T * D * M,
+        "fc1": (lambda: lib.ocm_op_linear(0, p(xn), p(w_fc1), p(b_m), None, p(out_h), T, M, D, 2, s()), 2.0 * T * D * M,
                 T * (D + M) * 2),
-        "fc1_nogelu": (lambda: lib.ocm_op_linear(p(xn), p(w_fc1), p(b_m), None, p(out_h), T, M, D, 3, s()),
+        "fc1_nogelu": (lambda: lib.ocm_op_linear(0, p(xn), p(w_fc1), p(b_m), None, p(out_h), T, M, D, 3, s()),
                        2.0 * T * D * M, T * (D + M) * 2),
-        "fc1_mainloop_only": (lambda: lib.ocm_op_linear(p(xn), p(w_fc1), p(b_m), None, p(out_h), T, M, D, 100, s()),
-                              2.0 * T * D * M, 0),
-        "fc2_mainloop_only": (lambda: lib.ocm_op_linear(p(hid), p(w_fc2), p(b_d), None, p(x32), T, D, M, 100, s()),
-                              2.0 * T * D * M, 0),
-        "fc2": (lambda: lib.ocm_op_linear(p(hid), p(w_fc2), p(b_d), p(x32), p(x32), T, D, M, 1, s()), 2.0 * T * D * M,
+        "fc2": (lambda: lib.ocm_op_linear(0, p(hid), p(w_fc2), p(b_d), p(x32), p(x32), T, D, M, 1, s()), 2.0 * T * D * M,
                 T * (M * 2 + D * 8)),
     }
     for spec in filter(None, a.lin.split(";")):
@@ -101,7 +97,7 @@ def main():
         la, lw, lb = rnd(m_, k_), rnd(n_, k_, scale=.02), rnd(n_, dtype=torch.float32)
         lo = torch.empty((m_, n_), dtype=torch.float32, device=dev)
         tests[f"lin{spec}"] = ((lambda la=la, lw=lw, lb=lb, lo=lo, m_=m_, n_=n_, k_=k_, e_=e_:
-                                lib.ocm_op_linear(p(la), p(lw), p(lb), p(lo), p(lo), m_, n_, k_, e_, s())),
+                                lib.ocm_op_linear(0, p(la), p(lw), p(lb), p(lo), p(lo), m_, n_, k_, e_, s())),
                                2.0 * m_ * n_ * k_, 0)
         only.add(f"lin{spec}") if only else None
     print(f"B={B} D={D} N={N} T={T}")

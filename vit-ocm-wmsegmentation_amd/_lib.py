@@ -10,10 +10,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OCM_VIT_LIB lets kernel experiments A/B two builds of the same ABI; the default is the in-tree build.
 LIB_PATH = os.environ.get("OCM_VIT_LIB") or os.path.join(_HERE, "libocm_vit.so")
 
-OCM_ABI_VERSION = 1
+OCM_ABI_VERSION = 2
 OCM_OK, OCM_EINVAL, OCM_ESTATE, OCM_EHIP, OCM_ENOMEM, OCM_ENAME = 0, 1, 2, 3, 4, 5
 
 OCM_PREC_BF16 = 0
+OCM_PREC_FP32 = 1
+PRECISIONS = {"bf16": OCM_PREC_BF16, "fp32": OCM_PREC_FP32}
 
 OCM_OUT_FEAT = 1 << 0
 OCM_OUT_ATTN = 1 << 1
@@ -89,12 +91,12 @@ SIGNATURES = {
     "ocm_vit_final_norm": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "ocm_op_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _vp]),
     "ocm_op_cast_bf16": (C.c_int, [_vp, _vp, _sz, _vp]),
-    "ocm_op_linear": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ocm_op_linear": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ocm_n_pad": (_i32, [_i32]),
-    "ocm_op_qkv_proj": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "ocm_op_attention": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
-    "ocm_op_attention_probs": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
-    "ocm_op_attention_rows": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "ocm_op_qkv_proj": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "ocm_op_attention": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "ocm_op_attention_probs": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "ocm_op_attention_rows": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp]),
     "ocm_op_attention_map": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ocm_prof_begin": (C.c_int, [C.c_uint32, _i32]),
     "ocm_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_i64)]),

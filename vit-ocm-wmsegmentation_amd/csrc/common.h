@@ -40,6 +40,11 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// exact fp32 MFMA (OCM_PREC_FP32): one f32 per lane per operand, k = lane >> 5
+__device__ __forceinline__ f32x16 mfma32f(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ bf16x8 cvt8(f32x4 lo, f32x4 hi) {
     bf16x8 r;
     r[0] = (bf16)lo[0]; r[1] = (bf16)lo[1]; r[2] = (bf16)lo[2]; r[3] = (bf16)lo[3];

@@ -118,6 +118,8 @@ struct BlockP {
 struct ocm_vit {
     ocm_vit_config cfg;
     int D, H, L, M, p, C, Kpe;
+    int prec;  // 0 = bf16 operands, 1 = fp32 operands (element size esz of matrices / activations)
+    size_t esz;
     std::vector<Param> params;
     std::vector<BlockP> blk;
     int cls, pe_w, pe_b, norm_g, norm_b;
@@ -126,7 +128,7 @@ struct ocm_vit {
 
     int add(const std::string &name, ParamKind kind, size_t count, size_t stored_elems) {
         Param pr{name, kind, count, arena_bytes, false};
-        const size_t bytes = stored_elems * (kind == P_F32 ? 4 : 2);
+        const size_t bytes = stored_elems * (kind == P_F32 ? 4 : esz);
         arena_bytes += (bytes + 255) & ~(size_t)255;
         params.push_back(pr);
         return (int)params.size() - 1;
@@ -148,11 +150,13 @@ extern "C" int ocm_vit_create(const ocm_vit_config *cfg, ocm_vit_t **out) {
     if (cfg->mlp_hidden <= 0 || cfg->mlp_hidden % 64)
         return fail(OCM_EINVAL, "mlp_hidden %d must be a multiple of 64", cfg->mlp_hidden);
     if (cfg->depth <= 0) return fail(OCM_EINVAL, "depth %d must be positive", cfg->depth);
-    if (cfg->precision != OCM_PREC_BF16)
-        return fail(OCM_EINVAL, "precision %d is not implemented (only OCM_PREC_BF16)", cfg->precision);
+    if (cfg->precision != OCM_PREC_BF16 && cfg->precision != OCM_PREC_FP32)
+        return fail(OCM_EINVAL, "precision %d is not one of OCM_PREC_BF16 / OCM_PREC_FP32", cfg->precision);
     ocm_vit *h = new ocm_vit();
     h->cfg = *cfg;
     h->D = D; h->H = H; h->L = cfg->depth; h->M = cfg->mlp_hidden; h->p = p; h->C = C; h->Kpe = C * p * p;
+    h->prec = cfg->precision == OCM_PREC_FP32 ? 1 : 0;
+    h->esz = h->prec ? 4 : 2;
     h->arena = nullptr;
     h->arena_bytes = 0;
     const size_t d = D, m = cfg->mlp_hidden;
@@ -204,17 +208,26 @@ extern "C" int ocm_vit_set_param(ocm_vit_t *h, const char *name, const float *de
         if (pr.kind == P_F32) {
             if (count != pr.count) return fail(OCM_EINVAL, "%s: expected %zu elements, got %zu", name, pr.count, count);
             HIP_TRY(hipMemcpyAsync(dst, dev_src, count * 4, hipMemcpyDeviceToDevice, s));
-        } else if (pr.kind == P_BF16) {
+        } else if (pr.kind == P_BF16) {  // matrix: bf16 copy, or fp32 copy in OCM_PREC_FP32
             if (count != pr.count) return fail(OCM_EINVAL, "%s: expected %zu elements, got %zu", name, pr.count, count);
-            HIP_TRY(launch_cast_bf16(dev_src, (bf16 *)dst, count, s));
+            if (h->prec)
+                HIP_TRY(hipMemcpyAsync(dst, dev_src, count * 4, hipMemcpyDeviceToDevice, s));
+            else
+                HIP_TRY(launch_cast_bf16(dev_src, (bf16 *)dst, count, s));
         } else {  // conv weight (D, C_ref, p, p)
             const size_t pp = (size_t)h->p * h->p, per = (size_t)h->D * pp;
             if (count == 0 || count % per) return fail(OCM_EINVAL, "%s: %zu elements is not (D=%d, C, %d, %d)", name, count, h->D, h->p, h->p);
             const int cref = (int)(count / per);
             if (cref == h->C) {
-                HIP_TRY(launch_cast_bf16(dev_src, (bf16 *)dst, count, s));
+                if (h->prec)
+                    HIP_TRY(hipMemcpyAsync(dst, dev_src, count * 4, hipMemcpyDeviceToDevice, s));
+                else
+                    HIP_TRY(launch_cast_bf16(dev_src, (bf16 *)dst, count, s));
             } else if (h->C == 1) {  // grayscale fold: W_eff = W.sum(dim=1)
-                HIP_TRY(launch_fold_cast_bf16(dev_src, (bf16 *)dst, h->D, cref, (int)pp, s));
+                if (h->prec)
+                    HIP_TRY(launch_fold_f32(dev_src, (float *)dst, h->D, cref, (int)pp, s));
+                else
+                    HIP_TRY(launch_fold_cast_bf16(dev_src, (bf16 *)dst, h->D, cref, (int)pp, s));
             } else {
                 return fail(OCM_EINVAL, "%s: weight has %d input channels, engine was created with in_chans=%d", name, cref, h->C);
             }
@@ -235,13 +248,13 @@ extern "C" int ocm_vit_params_ready(const ocm_vit_t *h) {
 // ------------------------------------------------------------------------------------------
 // workspace
 // ------------------------------------------------------------------------------------------
-struct Workspace {
+struct Workspace {  // E = bf16 (OCM_PREC_BF16) or float (OCM_PREC_FP32)
     float *x;     // [T][D]   fp32 residual stream
-    bf16 *xn;     // [T][D]   LayerNorm output (GEMM A operand)
-    bf16 *q, *k;  // [B*H][n_pad][64]
-    bf16 *vt;     // [B*H][64][n_pad]
-    bf16 *ctx;    // [T][D]   attention output, heads merged
-    bf16 *hid;    // [T][M]   GELU(fc1)
+    void *xn;     // [T][D] E LayerNorm output (GEMM A operand)
+    void *q, *k;  // [B*H][n_pad][64] E
+    void *vt;     // [B*H][64][n_pad] E
+    void *ctx;    // [T][D] E attention output, heads merged
+    void *hid;    // [T][M] E GELU(fc1)
     float *lse;   // [B*H][N]
     size_t bytes;
 };
@@ -255,13 +268,14 @@ static Workspace carve(const ocm_vit *h, int batch, int n, char *base) {
         return pch;
     };
     const size_t T = (size_t)batch * n, BH = (size_t)batch * h->H, np = ocm_n_pad(n);
+    const size_t e = h->esz;
     w.x = (float *)take(T * h->D * 4);
-    w.xn = (bf16 *)take(T * h->D * 2);
-    w.q = (bf16 *)take(BH * np * 64 * 2);
-    w.k = (bf16 *)take(BH * np * 64 * 2);
-    w.vt = (bf16 *)take(BH * np * 64 * 2);
-    w.ctx = (bf16 *)take(T * h->D * 2);
-    w.hid = (bf16 *)take(T * h->M * 2);
+    w.xn = take(T * h->D * e);
+    w.q = take(BH * np * 64 * e);
+    w.k = take(BH * np * 64 * e);
+    w.vt = take(BH * np * 64 * e);
+    w.ctx = take(T * h->D * e);
+    w.hid = take(T * h->M * e);
     w.lse = (float *)take(BH * n * 4);
     w.bytes = off;
     return w;
@@ -290,25 +304,26 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     const BlockP &bp = h->blk[i];
     const int D = h->D, H = h->H, T = batch * n, np = ocm_n_pad(n);
     const float eps = h->cfg.ln_eps, scale = h->cfg.qk_scale;
+    const int pc = h->prec;
     // y = attn(norm1(x))
-    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, true, T, D, eps, s)); }
-    { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(w.xn, h->ptr<bf16>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, w.vt, out_qkv, batch, n, np, H, s)); }
-    if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s)); }
+    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, !pc, T, D, eps, s)); }
+    { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, w.vt, out_qkv, batch, n, np, H, s)); }
+    if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s)); }
     if (attn_only) {
         if (out_attn) {
-            { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s)); }
-            { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
+            { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s)); }
+            { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
         }
         return OCM_OK;
     }
-    { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s)); }
-    if (out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
+    { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s)); }
+    if (out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
     // x = x + proj(ctx)
-    { PROF(OCM_K_PROJ, s); HIP_TRY(launch_linear(w.ctx, h->ptr<bf16>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s)); }
+    { PROF(OCM_K_PROJ, s); HIP_TRY(launch_linear(pc, w.ctx, h->ptr<char>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s)); }
     // x = x + fc2(gelu(fc1(norm2(x))))
-    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln2_g), h->ptr<float>(bp.ln2_b), w.xn, true, T, D, eps, s)); }
-    { PROF(OCM_K_FC1, s); HIP_TRY(launch_linear(w.xn, h->ptr<bf16>(bp.fc1_w), h->ptr<float>(bp.fc1_b), nullptr, w.hid, T, h->M, D, OCM_EPI_BIAS_GELU_BF16, s)); }
-    { PROF(OCM_K_FC2, s); HIP_TRY(launch_linear(w.hid, h->ptr<bf16>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s)); }
+    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln2_g), h->ptr<float>(bp.ln2_b), w.xn, !pc, T, D, eps, s)); }
+    { PROF(OCM_K_FC1, s); HIP_TRY(launch_linear(pc, w.xn, h->ptr<char>(bp.fc1_w), h->ptr<float>(bp.fc1_b), nullptr, w.hid, T, h->M, D, OCM_EPI_BIAS_GELU_BF16, s)); }
+    { PROF(OCM_K_FC2, s); HIP_TRY(launch_linear(pc, w.hid, h->ptr<char>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s)); }
     return OCM_OK;
 }
 
@@ -330,7 +345,7 @@ static int run_prepare(const ocm_vit *h, const ocm_vit_io *io, float *x, int n, 
                  io->batch, io->tile_h / h->p, io->tile_w / h->p, h->p, h->C};
     HIP_TRY(launch_cls_rows(h->ptr<float>(h->cls), io->pos_embed, x, io->batch, n, h->D, s));
     PROF(OCM_K_PATCH, s);
-    HIP_TRY(launch_patch_embed(pa, h->ptr<bf16>(h->pe_w), h->ptr<float>(h->pe_b), io->pos_embed, x, h->D, s));
+    HIP_TRY(launch_patch_embed(h->prec, pa, h->ptr<char>(h->pe_w), h->ptr<float>(h->pe_b), io->pos_embed, x, h->D, s));
     return OCM_OK;
 }
 
@@ -428,51 +443,66 @@ extern "C" int ocm_op_cast_bf16(const float *src, void *dst, size_t count, void 
     return OCM_OK;
 }
 
-extern "C" int ocm_op_linear(const void *a, const void *w, const float *bias, const float *resid, void *out,
-                             int32_t M, int32_t N, int32_t K, int32_t epilogue, void *stream) {
+static int prec_of(int32_t precision, int *pc) {
+    if (precision != OCM_PREC_BF16 && precision != OCM_PREC_FP32) return fail(OCM_EINVAL, "bad precision %d", precision);
+    *pc = precision == OCM_PREC_FP32;
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_linear(int32_t precision, const void *a, const void *w, const float *bias, const float *resid,
+                             void *out, int32_t M, int32_t N, int32_t K, int32_t epilogue, void *stream) {
+    int pc = 0, rc = prec_of(precision, &pc);
+    if (rc) return rc;
     if (!a || !w || !out) return fail(OCM_EINVAL, "null argument");
     if (M <= 0 || N <= 0 || N % 32 || K <= 0 || K % 64) return fail(OCM_EINVAL, "bad shape M=%d N=%d K=%d (N%%32, K%%64)", M, N, K);
-    if ((epilogue < 0 || epilogue > 3) && epilogue != 100) return fail(OCM_EINVAL, "bad epilogue %d", epilogue);
+    if (epilogue < 0 || epilogue > 3) return fail(OCM_EINVAL, "bad epilogue %d", epilogue);
     if (epilogue == OCM_EPI_BIAS_RESID_F32 && !resid) return fail(OCM_EINVAL, "residual epilogue without resid");
-    HIP_TRY(launch_linear((const bf16 *)a, (const bf16 *)w, bias, resid, out, M, N, K, epilogue, (hipStream_t)stream));
+    HIP_TRY(launch_linear(pc, a, w, bias, resid, out, M, N, K, epilogue, (hipStream_t)stream));
     return OCM_OK;
 }
 
-extern "C" int ocm_op_qkv_proj(const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
-                               float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads, void *stream) {
+extern "C" int ocm_op_qkv_proj(int32_t precision, const void *a, const void *w, const float *bias, void *q, void *k,
+                               void *vt, float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads, void *stream) {
+    int pc = 0, rc = prec_of(precision, &pc);
+    if (rc) return rc;
     if (!a || !w || !bias || !q || !k || !vt) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_qkv((const bf16 *)a, (const bf16 *)w, bias, (bf16 *)q, (bf16 *)k, (bf16 *)vt, qkv_f32, batch, n_tokens,
-                       ocm_n_pad(n_tokens), heads, (hipStream_t)stream));
+    HIP_TRY(launch_qkv(pc, a, w, bias, q, k, vt, qkv_f32, batch, n_tokens, ocm_n_pad(n_tokens), heads, (hipStream_t)stream));
     return OCM_OK;
 }
 
-extern "C" int ocm_op_attention(const void *q, const void *k, const void *vt, void *ctx, float *lse2, int32_t batch,
-                                int32_t n_tokens, int32_t heads, float scale, void *stream) {
+extern "C" int ocm_op_attention(int32_t precision, const void *q, const void *k, const void *vt, void *ctx, float *lse2,
+                                int32_t batch, int32_t n_tokens, int32_t heads, float scale, void *stream) {
+    int pc = 0, rc = prec_of(precision, &pc);
+    if (rc) return rc;
     if (!q || !k || !vt) return fail(OCM_EINVAL, "null argument");
     if (!ctx && !lse2) return fail(OCM_EINVAL, "nothing to compute: ctx and lse2 are both null");
     if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_attention((const bf16 *)q, (const bf16 *)k, (const bf16 *)vt, (bf16 *)ctx, lse2, batch, n_tokens,
-                             ocm_n_pad(n_tokens), heads, scale, (hipStream_t)stream));
+    HIP_TRY(launch_attention(pc, q, k, vt, ctx, lse2, batch, n_tokens, ocm_n_pad(n_tokens), heads, scale,
+                             (hipStream_t)stream));
     return OCM_OK;
 }
 
-extern "C" int ocm_op_attention_probs(const void *q, const void *k, const float *lse2, float *attn, int32_t batch,
-                                      int32_t n_tokens, int32_t heads, float scale, void *stream) {
+extern "C" int ocm_op_attention_probs(int32_t precision, const void *q, const void *k, const float *lse2, float *attn,
+                                      int32_t batch, int32_t n_tokens, int32_t heads, float scale, void *stream) {
+    int pc = 0, rc = prec_of(precision, &pc);
+    if (rc) return rc;
     if (!q || !k || !lse2 || !attn) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_attention_probs((const bf16 *)q, (const bf16 *)k, lse2, attn, batch, n_tokens, ocm_n_pad(n_tokens),
-                                   heads, scale, (hipStream_t)stream));
+    HIP_TRY(launch_attention_probs(pc, q, k, lse2, attn, batch, n_tokens, ocm_n_pad(n_tokens), heads, scale,
+                                   (hipStream_t)stream));
     return OCM_OK;
 }
 
-extern "C" int ocm_op_attention_rows(const void *q, const void *k, const int32_t *query_rows, int32_t n_rows,
-                                     float *rows, int32_t batch, int32_t n_tokens, int32_t heads, float scale,
-                                     void *stream) {
+extern "C" int ocm_op_attention_rows(int32_t precision, const void *q, const void *k, const int32_t *query_rows,
+                                     int32_t n_rows, float *rows, int32_t batch, int32_t n_tokens, int32_t heads,
+                                     float scale, void *stream) {
+    int pc = 0, rc = prec_of(precision, &pc);
+    if (rc) return rc;
     if (!q || !k || !rows) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || n_tokens <= 1 || heads <= 0 || n_rows <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_attention_rows((const bf16 *)q, (const bf16 *)k, query_rows, n_rows, rows, batch, n_tokens,
-                                  ocm_n_pad(n_tokens), heads, scale, (hipStream_t)stream));
+    HIP_TRY(launch_attention_rows(pc, q, k, query_rows, n_rows, rows, batch, n_tokens, ocm_n_pad(n_tokens), heads, scale,
+                                  (hipStream_t)stream));
     return OCM_OK;
 }
 

@@ -1,18 +1,24 @@
-// gemm_core.h — bf16 MFMA tile GEMM for the ViT projections (gfx950).
+// gemm_core.h — MFMA tile GEMM for the ViT projections (gfx950).
 //
 //   C[m][n] = sum_k A[m][k] * W[n][k]        (nn.Linear layout: W is [N][K], K contiguous)
 //
-// One workgroup = WAVES_M x WAVES_N wavefronts computes a BM x BN tile with
-// v_mfma_f32_32x32x16_bf16; K is walked in 64-wide steps through a double-buffered,
-// XOR-swizzled LDS image (common.h: lds_off).  Staging is register-staged with the
-// issue-early / write-late split: the global loads of K-step t+1 are issued before the
-// MFMAs of step t and committed to the other LDS buffer after them, one barrier per step.
+// One workgroup = WAVES_M x WAVES_N wavefronts computes a BM x BN tile; K is walked in steps of one
+// 128-byte LDS row (64 bf16 or 32 fp32 elements) through a double-buffered, XOR-swizzled LDS image
+// (common.h: lds_off). The operand element type selects the matrix instruction:
+//   bf16  : v_mfma_f32_32x32x16_bf16   (OCM_PREC_BF16, the fast path)
+//   float : v_mfma_f32_32x32x2_f32     (OCM_PREC_FP32: exact fp32 products, 1/16 of the bf16 rate)
+// Both accumulate in fp32 and share the C/D register layout, the LDS geometry, the staging code and
+// every epilogue.
+//
+// Staging is register-staged with the issue-early / commit-late split and one LDS-only barrier per
+// step. When K is a compile-time constant (KSTEPS > 0, even) two register slots give a prefetch
+// distance of two steps with an unconditional load stream, so hipcc counts its own `vmcnt(N)` waits.
 //
 // The A operand comes through a loader policy so the same main loop serves
-//   - plain bf16 activations (RowLoader) and
+//   - plain row-major activations (RowLoader) and
 //   - the im2col-free patch gather from fp32 image planes (PatchLoader, kernels_gemm.hip).
-// The accumulator can be produced transposed (SWAP): acc^T has the token index on the
-// lanes, which is how the V projection is written key-contiguous (V^T) with coalesced stores.
+// The accumulator can be produced transposed (SWAP): acc^T has the token index on the lanes, which is
+// how the V projection is written key-contiguous (V^T) with coalesced stores.
 #pragma once
 #include "common.h"
 
@@ -28,23 +34,85 @@ struct GemmCfg {
     static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging must divide evenly");
 };
 
-// A operand = bf16 row-major activations.
-struct RowLoader {
-    const bf16 *A;
-    int64_t lda;
-    typedef const bf16 *Handle;
-    typedef bf16x8 Raw;
-    __device__ __forceinline__ Handle row(int m) const { return A + (int64_t)m * lda; }
-    __device__ __forceinline__ Raw load(Handle h, int k) const { return *(const bf16x8 *)(h + k); }
-    __device__ __forceinline__ static bf16x8 finish(const Raw &r) { return r; }
+// operand element traits: a 16-byte chunk holds EPC elements, an LDS row (one K step) KROW elements
+template <class E>
+struct Elem;
+template <>
+struct Elem<bf16> {
+    typedef bf16x8 Chunk;
+    static constexpr int EPC = 8, KROW = 64;
+};
+template <>
+struct Elem<float> {
+    typedef f32x4 Chunk;
+    static constexpr int EPC = 4, KROW = 32;
 };
 
-// Main loop. acc[i][j] is the 32x32 tile at rows wm*WM+32i, cols wn*WN+32j of the block
-// tile; with SWAP the register/lane roles of that tile are transposed (lane = row m).
-template <class Cfg, bool SWAP, int KSTEPS, class ALoad>
-__device__ __forceinline__ void gemm_mainloop(const ALoad &al, const bf16 *__restrict__ W, int64_t ldw,
-                                              int m0, int n0, int M, int N, int K, char *smem,
-                                              f32x16 (&acc)[Cfg::TM][Cfg::TN], const float *__restrict__ bias) {
+// A operand = row-major activations of element type E.
+template <class E>
+struct RowLoader {
+    const E *A;
+    int64_t lda;
+    typedef const E *Handle;
+    typedef typename Elem<E>::Chunk Raw;
+    __device__ __forceinline__ Handle row(int m) const { return A + (int64_t)m * lda; }
+    __device__ __forceinline__ Raw load(Handle h, int k) const { return *(const Raw *)(h + k); }
+    __device__ __forceinline__ static Raw finish(const Raw &r) { return r; }
+};
+
+// One K step of MFMAs on the LDS tiles at Ab / Bb (already offset to the wave's rows).
+template <class Cfg, class E, bool SWAP>
+__device__ __forceinline__ void mma_step(const char *Ab, const char *Bb, int r, int h,
+                                         f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    if constexpr (sizeof(E) == 2) {
+        // rows wm*WM + 32i + r: the swizzle term (row>>1)&7 only depends on r because the wave / tile row
+        // offsets are multiples of 32. Lane (r, h) holds k = 16s + 8h .. +7 of row r.
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8 *)(Ab + i * 32 * 128 + lds_off(r, 2 * s + h));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8 *)(Bb + j * 32 * 128 + lds_off(r, 2 * s + h));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = SWAP ? mfma32(b[j], a[i], acc[i][j]) : mfma32(a[i], b[j], acc[i][j]);
+        }
+    } else {
+        // v_mfma_f32_32x32x2_f32: lane (r, h) supplies A[r][k_h] and B[k_h][r] for the instruction's two
+        // k values. Lane half h reads chunk c + 4h of its row (k = 16h + 4c .. +3): each 16-B LDS read
+        // feeds 4 MFMAs whose k pairs are {4c + e, 16 + 4c + e} — any pairing is valid as long as A
+        // and B use the same one, which they do (same chunk index on both operands).
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const f32x4 *)(Ab + i * 32 * 128 + lds_off(r, c + 4 * h));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *(const f32x4 *)(Bb + j * 32 * 128 + lds_off(r, c + 4 * h));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = SWAP ? mfma32f(b[j][e], a[i][e], acc[i][j]) : mfma32f(a[i][e], b[j][e], acc[i][j]);
+        }
+    }
+}
+
+// Main loop. acc[i][j] is the 32x32 tile at rows wm*WM+32i, cols wn*WN+32j of the block tile; with
+// SWAP the register/lane roles of that tile are transposed (lane = row m). KSTEPS = K / KROW when K
+// is known at compile time (0 = runtime K).
+template <class Cfg, class E, bool SWAP, int KSTEPS, class ALoad>
+__device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restrict__ W, int64_t ldw, int m0, int n0,
+                                              int M, int N, int K, char *smem, f32x16 (&acc)[Cfg::TM][Cfg::TN],
+                                              const float *__restrict__ bias) {
+    typedef typename Elem<E>::Chunk Chunk;
+    constexpr int EPC = Elem<E>::EPC, KROW = Elem<E>::KROW;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
     constexpr int A_CH = Cfg::A_CH, B_CH = Cfg::B_CH, TM = Cfg::TM, TN = Cfg::TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -54,36 +122,41 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const bf16 *__res
     char *Bs = smem + 2 * BM * 128;
 
     typename ALoad::Handle a_h[A_CH];
-    const bf16 *b_h[B_CH];
+    const E *b_h[B_CH];
     int a_off[A_CH], b_off[B_CH], a_k[A_CH], b_k[B_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
         const int q = tid + NT * i, row = q >> 3, c = q & 7;
         a_h[i] = al.row(min(m0 + row, M - 1));
         a_off[i] = lds_off(row, c);
-        a_k[i] = c * 8;
+        a_k[i] = c * EPC;
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
         const int q = tid + NT * i, row = q >> 3, c = q & 7;
         b_h[i] = W + (int64_t)min(n0 + row, N - 1) * ldw;
         b_off[i] = lds_off(row, c);
-        b_k[i] = c * 8;
+        b_k[i] = c * EPC;
     }
-
-    typename ALoad::Raw ra[A_CH];
-    bf16x8 rb[B_CH];
-    auto issue = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) ra[i] = al.load(a_h[i], k0 + a_k[i]);
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) rb[i] = *(const bf16x8 *)(b_h[i] + k0 + b_k[i]);
+    struct Slot {
+        typename ALoad::Raw a[A_CH];
+        Chunk b[B_CH];
     };
-    auto commit = [&](int buf) {
+    auto issue = [&](Slot &sl, int k0) {
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) *(bf16x8 *)(As + buf * BM * 128 + a_off[i]) = ALoad::finish(ra[i]);
+        for (int i = 0; i < A_CH; ++i) sl.a[i] = al.load(a_h[i], k0 + a_k[i]);
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) *(bf16x8 *)(Bs + buf * BN * 128 + b_off[i]) = rb[i];
+        for (int i = 0; i < B_CH; ++i) sl.b[i] = *(const Chunk *)(b_h[i] + k0 + b_k[i]);
+    };
+    auto commit = [&](int buf, const Slot &sl) {
+#pragma unroll
+        for (int i = 0; i < A_CH; ++i) *(Chunk *)(As + buf * BM * 128 + a_off[i]) = ALoad::finish(sl.a[i]);
+#pragma unroll
+        for (int i = 0; i < B_CH; ++i) *(Chunk *)(Bs + buf * BN * 128 + b_off[i]) = sl.b[i];
+    };
+    auto compute = [&](int buf) {
+        mma_step<Cfg, E, SWAP>(As + buf * BM * 128 + (wm * Cfg::WM) * 128, Bs + buf * BN * 128 + (wn * Cfg::WN) * 128, r,
+                               h, acc);
     };
 
     // Accumulators start at the bias (one load per column / register row, issued together with the
@@ -108,89 +181,41 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const bf16 *__res
     }
 
     if constexpr (KSTEPS > 0 && KSTEPS % 2 == 0) {
-        // K known at compile time (KSTEPS 64-wide steps, even): two register staging slots give a
-        // prefetch distance of TWO steps — the tile committed to LDS in step t was requested in step
-        // t-2 (L2 latency under load is ~1 us, more than one step). The stream is unconditional
-        // (indices past the end re-read the last tile into a dead slot) and the trip count is a
-        // constant, so hipcc can count its own `s_waitcnt vmcnt(N)` instead of draining to 0.
-        struct Slot {
-            typename ALoad::Raw a[A_CH];
-            bf16x8 b[B_CH];
-        };
-        auto issue2 = [&](Slot &sl, int t) {
-            const int k0 = min(t, KSTEPS - 1) << 6;
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) sl.a[i] = al.load(a_h[i], k0 + a_k[i]);
-#pragma unroll
-            for (int i = 0; i < B_CH; ++i) sl.b[i] = *(const bf16x8 *)(b_h[i] + k0 + b_k[i]);
-        };
-        auto commit2 = [&](int buf, const Slot &sl) {
-#pragma unroll
-            for (int i = 0; i < A_CH; ++i) *(bf16x8 *)(As + buf * BM * 128 + a_off[i]) = ALoad::finish(sl.a[i]);
-#pragma unroll
-            for (int i = 0; i < B_CH; ++i) *(bf16x8 *)(Bs + buf * BN * 128 + b_off[i]) = sl.b[i];
-        };
-        auto compute = [&](int buf) {
-            const char *Ab = As + buf * BM * 128 + (wm * Cfg::WM) * 128;
-            const char *Bb = Bs + buf * BN * 128 + (wn * Cfg::WN) * 128;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                bf16x8 a[TM], b[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8 *)(Ab + i * 32 * 128 + lds_off(r, 2 * s + h));
-#pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8 *)(Bb + j * 32 * 128 + lds_off(r, 2 * s + h));
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = SWAP ? mfma32(b[j], a[i], acc[i][j]) : mfma32(a[i], b[j], acc[i][j]);
-            }
-        };
+        // Two register slots: the tile committed to LDS in step t was requested in step t-2 (L2 latency
+        // under load is ~1 us, more than one step). The stream is unconditional (indices past the end
+        // re-read the last tile into a dead slot) and the trip count is a constant, so hipcc counts its
+        // own `s_waitcnt vmcnt(N)` instead of draining to 0.
+        auto issue2 = [&](Slot &sl, int t) { issue(sl, min(t, KSTEPS - 1) * KROW); };
         Slot s0, s1;
         issue2(s0, 0);
         issue2(s1, 1);
-        commit2(0, s0);
+        commit(0, s0);
         issue2(s0, 2);  // s1 = tile 1, s0 = tile 2
         lds_barrier();
         for (int t = 0; t < KSTEPS; t += 2) {
-            compute(0);      // tile t (even tiles live in buffer 0)
-            commit2(1, s1);  // tile t+1
+            compute(0);     // tile t (even tiles live in buffer 0)
+            commit(1, s1);  // tile t+1
             issue2(s1, t + 3);
             lds_barrier();
-            compute(1);      // tile t+1
-            commit2(0, s0);  // tile t+2 (a dead duplicate after the last tile)
+            compute(1);     // tile t+1
+            commit(0, s0);  // tile t+2 (a dead duplicate after the last tile)
             issue2(s0, t + 4);
             lds_barrier();
         }
-        return;
-    }
-    const int nt = K >> 6;
-    issue(0);
-    commit(0);
-    lds_barrier();
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) issue((t + 1) << 6);
-        const char *Ab = As + buf * BM * 128 + (wm * Cfg::WM) * 128;
-        const char *Bb = Bs + buf * BN * 128 + (wn * Cfg::WN) * 128;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            bf16x8 a[TM], b[TN];
-            // rows wm*WM + 32i + r: the swizzle term (row>>1)&7 only depends on r because
-            // the wave/tile row offsets are multiples of 32.
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8 *)(Ab + i * 32 * 128 + lds_off(r, 2 * s + h));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8 *)(Bb + j * 32 * 128 + lds_off(r, 2 * s + h));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = SWAP ? mfma32(b[j], a[i], acc[i][j]) : mfma32(a[i], b[j], acc[i][j]);
-        }
-        if (t + 1 < nt) commit(buf ^ 1);
+    } else {
+        // runtime K: one-step prefetch
+        const int nt = K / KROW;
+        Slot s0;
+        issue(s0, 0);
+        commit(0, s0);
         lds_barrier();
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            if (t + 1 < nt) issue(s0, (t + 1) * KROW);
+            compute(buf);
+            if (t + 1 < nt) commit(buf ^ 1, s0);
+            lds_barrier();
+        }
     }
 }
 
@@ -222,16 +247,16 @@ __device__ __forceinline__ void stage_acc(const f32x16 (&acc)[Cfg::TM][Cfg::TN],
 
 // Generic kernel: grid = tiles_m * tiles_n workgroups (linear, XCD-remapped so the
 // workgroups that share an A row panel sit on one XCD's L2).
-template <class Cfg, bool SWAP, int KSTEPS, class ALoad, class Epi>
-__global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const bf16 *__restrict__ W, int64_t ldw,
-                                                       int M, int N, int K, Epi epi) {
+template <class Cfg, class E, bool SWAP, int KSTEPS, class ALoad, class Epi>
+__global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const E *__restrict__ W, int64_t ldw, int M, int N,
+                                                       int K, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
-    gemm_mainloop<Cfg, SWAP, KSTEPS>(al, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
+    gemm_mainloop<Cfg, E, SWAP, KSTEPS>(al, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
     stage_acc<Cfg, SWAP>(acc, smem);
     epi.template run<Cfg>((const float *)smem, m0, n0);
 }

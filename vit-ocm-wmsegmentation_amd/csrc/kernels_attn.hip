@@ -341,8 +341,8 @@ __global__ __launch_bounds__(512, 4) void attn_small_kernel(const bf16 *__restri
     }
 }
 
-hipError_t launch_attention(const bf16 *q, const bf16 *k, const bf16 *vt, bf16 *ctx, float *lse2, int batch,
-                            int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
+static hipError_t launch_attention_bf16(const bf16 *q, const bf16 *k, const bf16 *vt, bf16 *ctx, float *lse2, int batch,
+                                        int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
     static const char *force_stream = getenv("OCM_ATTN_STREAM");  // development switch
     if (n_tokens <= 256 && !force_stream) {
         const dim3 grid(batch * heads), block(512);
@@ -410,40 +410,280 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16 *__restrict_
     }
 }
 
-hipError_t launch_attention_probs(const bf16 *q, const bf16 *k, const float *lse2, float *attn, int batch,
+// ------------------------------------------------------------------------------------------
+// OCM_PREC_FP32: the same algorithms on fp32 q / k / V^T with v_mfma_f32_32x32x2_f32 (exact fp32
+// products). Lane (r, h) supplies one float per operand per instruction (k index = h); a 16-byte read
+// of chunk c + 4h of a 128-byte row-half feeds 4 MFMAs. No key permutation is needed: register e of
+// the S^T accumulator holds keys acc_row32(e, 0) and acc_row32(e, 1) on the two lane halves, which
+// is exactly one instruction's k pair when p[e] is used as the B operand of O^T += V^T P^T.
+// LDS tiles: 64 keys x 64 d fp32 = 128 rows of 128 B (row = 2*key + half); V^T likewise (row = 2*d + half).
+template <bool WANT_O>
+__global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float *__restrict__ Q, const float *__restrict__ Kk,
+                                                           const float *__restrict__ Vt, float *__restrict__ ctx,
+                                                           float *__restrict__ lse2, int N, int npad, int H,
+                                                           float scale2) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 128 * 128];  // K[2] | Vt[2], 16 KiB each
+    char *Ks = smem, *Vs = smem + 2 * 16384;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const bool active = q0 < N;
+    const float *Qb = Q + (int64_t)bh * npad * 64;
+    const float *Kb = Kk + (int64_t)bh * npad * 64;
+    const float *Vb = Vt + (int64_t)bh * 64 * npad;
+
+    f32x4 qf[2][4];  // [half of d][chunk c]: d = 32*half + 16*h + 4*c + e
+    {
+        const int qrow = min(q0 + r, N - 1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qf[hf][c] = *(const f32x4 *)(Qb + (int64_t)qrow * 64 + 32 * hf + 16 * h + 4 * c);
+    }
+    // staging: 1024 K chunks + 1024 V^T chunks of 16 B per tile, 256 threads -> 4 + 4 each
+    f32x4 rk[4], rv[4];
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qd = tid + 256 * i, row = qd >> 3, c = qd & 7;  // LDS row (0..127), chunk
+            const int key = min(kt * 64 + (row >> 1), N - 1);
+            rk[i] = *(const f32x4 *)(Kb + (int64_t)key * 64 + (row & 1) * 32 + c * 4);
+            const int d = row >> 1, key0 = kt * 64 + (row & 1) * 32 + c * 4;  // V^T row d, 4 keys
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (key0 < npad) {  // npad % 8 == 0 and key0 % 4 == 0: the 16-B load stays inside the row
+                v = *(const f32x4 *)(Vb + (int64_t)d * npad + key0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (key0 + e >= N) v[e] = 0.f;  // padding keys: exact zeros
+            }
+            rv[i] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qd = tid + 256 * i, row = qd >> 3, c = qd & 7;
+            *(f32x4 *)(Ks + buf * 16384 + lds_off(row, c)) = rk[i];
+            *(f32x4 *)(Vs + buf * 16384 + lds_off(row, c)) = rv[i];
+        }
+    };
+
+    f32x16 O[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[0][e] = O[1][e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int ntiles = (N + 63) >> 6;
+    issue(0);
+    commit(0);
+    lds_barrier();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles) issue(kt + 1);
+        if (active) {
+            const char *Kt = Ks + buf * 16384, *Vtile = Vs + buf * 16384;
+            f32x16 S[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) S[sub][e] = 0.f;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x4 a = *(const f32x4 *)(Kt + lds_off(2 * (sub * 32 + r) + hf, c + 4 * h));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) S[sub] = mfma32f(a[e], qf[hf][c][e], S[sub]);
+                    }
+            }
+            if ((kt + 1) * 64 > N) {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (kt * 64 + sub * 32 + acc_row32(e, h) >= N) S[sub][e] = -INFINITY;
+            }
+            float mx = fmaxf(S[0][0], S[1][0]);
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(S[0][e], S[1][e]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx * scale2);
+            const float alpha = fast_exp2(m - mn);
+            m = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = fast_exp2(fmaf(S[sub][e], scale2, -mn));
+                    S[sub][e] = p;
+                    ps += p;
+                }
+            l = fmaf(l, alpha, ps);
+            if (WANT_O) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    O[0][e] *= alpha;
+                    O[1][e] *= alpha;
+                }
+                // registers 4g..4g+3 of S[sub] = keys sub*32 + 8g + 4h + (0..3): one 16-B read of V^T
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int chunk = sub * 8 + 2 * g + h;  // 4-key chunk index inside the 64-key row
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const f32x4 a = *(const f32x4 *)(Vtile + lds_off(2 * (db * 32 + r) + (chunk >> 3), chunk & 7));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) O[db] = mfma32f(a[e], S[sub][4 * g + e], O[db]);
+                        }
+                    }
+            }
+        }
+        if (kt + 1 < ntiles) commit(buf ^ 1);
+        lds_barrier();
+    }
+    if (!active) return;
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const int qrow = q0 + r;
+    if (qrow < N) {
+        if (lse2 && h == 0) lse2[(int64_t)bh * N + qrow] = m + __log2f(lt);
+        if (WANT_O) {
+            const float inv = 1.0f / lt;
+            const int b = bh / H, head = bh - b * H;
+            float *dst = ctx + ((int64_t)b * N + qrow) * (H * 64) + head * 64;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = O[db][4 * g + e] * inv;
+                    *(f32x4 *)(dst + db * 32 + 8 * g + 4 * h) = o;
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_probs_f32_kernel(const float *__restrict__ Q, const float *__restrict__ Kk,
+                                                             const float *__restrict__ lse2, float *__restrict__ attn,
+                                                             int N, int npad, float scale2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    if (q0 >= N) return;
+    const float *Qb = Q + (int64_t)bh * npad * 64;
+    const float *Kb = Kk + (int64_t)bh * npad * 64;
+    f32x4 qf[2][4];
+    {
+        const int qrow = min(q0 + r, N - 1);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) qf[hf][c] = *(const f32x4 *)(Qb + (int64_t)qrow * 64 + 32 * hf + 16 * h + 4 * c);
+    }
+    float lr[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lr[e] = lse2[(int64_t)bh * N + min(q0 + acc_row32(e, h), N - 1)];
+    float *out = attn + (int64_t)bh * N * N;
+    const int ktiles = (N + 31) >> 5;
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int key = min(kt * 32 + r, N - 1);
+        f32x16 S;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] = 0.f;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 kf = *(const f32x4 *)(Kb + (int64_t)key * 64 + 32 * hf + 16 * h + 4 * c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S = mfma32f(qf[hf][c][e], kf[e], S);  // rows = queries, col (lane) = key
+            }
+        if (kt * 32 + r < N) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qrow = q0 + acc_row32(e, h);
+                if (qrow < N) out[(int64_t)qrow * N + kt * 32 + r] = fast_exp2(S[e] * scale2 - lr[e]);
+            }
+        }
+    }
+}
+
+hipError_t launch_attention(int prec, const void *q, const void *k, const void *vt, void *ctx, float *lse2, int batch,
+                            int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
+    if (!prec)
+        return launch_attention_bf16((const bf16 *)q, (const bf16 *)k, (const bf16 *)vt, (bf16 *)ctx, lse2, batch,
+                                     n_tokens, n_pad, heads, scale, s);
+    const int qtiles = (n_tokens + 31) / 32;
+    const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
+    if (ctx)
+        attn_fwd_f32_kernel<true><<<grid, block, 0, s>>>((const float *)q, (const float *)k, (const float *)vt,
+                                                         (float *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+    else
+        attn_fwd_f32_kernel<false><<<grid, block, 0, s>>>((const float *)q, (const float *)k, (const float *)vt,
+                                                          (float *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention_probs(int prec, const void *q, const void *k, const float *lse2, float *attn, int batch,
                                   int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
     const int qtiles = (n_tokens + 31) / 32;
     const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
-    attn_probs_kernel<<<grid, block, 0, s>>>(q, k, lse2, attn, n_tokens, n_pad, scale * LOG2E);
+    if (prec)
+        attn_probs_f32_kernel<<<grid, block, 0, s>>>((const float *)q, (const float *)k, lse2, attn, n_tokens, n_pad,
+                                                     scale * LOG2E);
+    else
+        attn_probs_kernel<<<grid, block, 0, s>>>((const bf16 *)q, (const bf16 *)k, lse2, attn, n_tokens, n_pad,
+                                                 scale * LOG2E);
     return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
 // rows[b][h][i][j-1] = softmax_j(q[query_i] . k[j] * scale), j = 1..N-1   (utils.py:232)
-__global__ __launch_bounds__(64) void attn_rows_kernel(const bf16 *__restrict__ Q, const bf16 *__restrict__ Kk,
+__device__ __forceinline__ void load8(const bf16 *p, float (&o)[8]) {
+    const bf16x8 t = *(const bf16x8 *)p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)t[e];
+}
+__device__ __forceinline__ void load8(const float *p, float (&o)[8]) {
+    const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        o[e] = a[e];
+        o[4 + e] = b[e];
+    }
+}
+
+template <class E>
+__global__ __launch_bounds__(64) void attn_rows_kernel(const E *__restrict__ Q, const E *__restrict__ Kk,
                                                        const int32_t *__restrict__ query_rows, int n_rows,
                                                        float *__restrict__ rows, int N, int npad, float scale2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *sc = (float *)smem;  // N scores
     const int lane = threadIdx.x, bh = blockIdx.y, qi = blockIdx.x;
     const int query = query_rows ? query_rows[qi] : 0;
-    const bf16 *qp = Q + ((int64_t)bh * npad + query) * 64;
+    const E *qp = Q + ((int64_t)bh * npad + query) * 64;
     float qv[64];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const bf16x8 t = *(const bf16x8 *)(qp + c * 8);
+        float t[8];
+        load8(qp + c * 8, t);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qv[c * 8 + e] = (float)t[e];
+        for (int e = 0; e < 8; ++e) qv[c * 8 + e] = t[e];
     }
     float mx = -INFINITY;
     for (int key = lane; key < N; key += 64) {
-        const bf16 *kp = Kk + ((int64_t)bh * npad + key) * 64;
+        const E *kp = Kk + ((int64_t)bh * npad + key) * 64;
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const bf16x8 t = *(const bf16x8 *)(kp + c * 8);
+            float t[8];
+            load8(kp + c * 8, t);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc = fmaf(qv[c * 8 + e], (float)t[e], acc);
+            for (int e = 0; e < 8; ++e) acc = fmaf(qv[c * 8 + e], t[e], acc);
         }
         acc *= scale2;
         sc[key] = acc;
@@ -464,12 +704,17 @@ __global__ __launch_bounds__(64) void attn_rows_kernel(const bf16 *__restrict__ 
     for (int key = 1 + lane; key < N; key += 64) dst[key - 1] = sc[key] * inv;
 }
 
-hipError_t launch_attention_rows(const bf16 *q, const bf16 *k, const int32_t *query_rows, int n_rows, float *rows,
-                                 int batch, int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
+hipError_t launch_attention_rows(int prec, const void *q, const void *k, const int32_t *query_rows, int n_rows,
+                                 float *rows, int batch, int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
     if (n_rows <= 0) return hipSuccess;
     const dim3 grid(n_rows, batch * heads), block(64);
-    attn_rows_kernel<<<grid, block, (size_t)n_tokens * sizeof(float), s>>>(q, k, query_rows, n_rows, rows, n_tokens,
-                                                                           n_pad, scale * LOG2E);
+    const size_t lds = (size_t)n_tokens * sizeof(float);
+    if (prec)
+        attn_rows_kernel<float><<<grid, block, lds, s>>>((const float *)q, (const float *)k, query_rows, n_rows, rows,
+                                                         n_tokens, n_pad, scale * LOG2E);
+    else
+        attn_rows_kernel<bf16><<<grid, block, lds, s>>>((const bf16 *)q, (const bf16 *)k, query_rows, n_rows, rows,
+                                                        n_tokens, n_pad, scale * LOG2E);
     return hipGetLastError();
 }
 

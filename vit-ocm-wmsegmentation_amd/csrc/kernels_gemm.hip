@@ -3,22 +3,28 @@
 //   qkv projection   (Attention.forward :80)
 //   proj / fc2 + residual (Attention.forward :88, Block.forward :110-111, Mlp.forward :61)
 //   fc1 + exact-erf GELU  (Mlp.forward :58-59)
-// All share gemm_core.h's main loop; they differ in the A loader and the epilogue.
-#include <stdlib.h>
-#include <string.h>
-
+// All share gemm_core.h's main loop; they differ in the A loader and the epilogue. Every kernel exists
+// for two operand element types: bf16 (OCM_PREC_BF16) and float (OCM_PREC_FP32, exact-fp32 MFMA).
 #include "gemm_core.h"
-#include "gemm_panel.h"
 #include "launch.h"
+
+typedef GemmCfg<128, 128, 2, 2> Cfg128x128;
+typedef GemmCfg<64, 128, 2, 2> Cfg64x128;
+typedef GemmCfg<64, 64, 2, 2> Cfg64x64;
+
+// 16-byte store of 16/sizeof(OE) consecutive outputs taken from fp32 values
+__device__ __forceinline__ void store_chunk(bf16 *dst, const f32x4 &v0, const f32x4 &v1) { *(bf16x8 *)dst = cvt8(v0, v1); }
+__device__ __forceinline__ void store_chunk(float *dst, const f32x4 &v0, const f32x4 &) { *(f32x4 *)dst = v0; }
 
 // ------------------------------------------------------------------------------------------
 // nn.Linear epilogues
 // ------------------------------------------------------------------------------------------
-// out = epilogue(acc) with the bias already in the accumulator (gemm_mainloop). fp32 outputs move
-// 16 B (4 columns) per lane, bf16 outputs 16 B (8 columns) per lane. The residual of ALL of a lane's
-// chunks is requested in one burst before the first use (one exposed L2 round trip instead of one per
-// unrolled group); `resid` may alias `out` (each element is read then written by the same lane).
-template <int MODE>
+// out = epilogue(acc) with the bias already in the accumulator (gemm_mainloop).
+//   MODE 0: fp32 out            MODE 1: fp32 out = resid + acc (resid may alias out)
+//   MODE 2: OE out = gelu(acc)  MODE 3: OE out = acc          (OE = operand type of the next GEMM)
+// Every lane moves 16 B per chunk. The residual of ALL of a lane's chunks is requested in one burst
+// before the first use (one exposed L2 round trip instead of one per unrolled group).
+template <int MODE, class OE>
 struct EpiLinear {
     const float *bias;
     const float *resid;
@@ -28,9 +34,9 @@ struct EpiLinear {
     template <class Cfg>
     __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
-        constexpr bool OUT_BF16 = (MODE == 2 || MODE == 3);
-        constexpr int W = OUT_BF16 ? 8 : 4;  // columns per lane
-        constexpr int CPR = BN / W;          // chunks per row
+        constexpr bool ACT_OUT = (MODE == 2 || MODE == 3);
+        constexpr int W = ACT_OUT ? 16 / (int)sizeof(OE) : 4;  // columns per lane
+        constexpr int CPR = BN / W;                            // chunks per row
         constexpr int ITERS = BM * CPR / NT;
         static_assert(NT % CPR == 0, "a lane keeps one column chunk");
         const int col = (threadIdx.x % CPR) * W, row0 = threadIdx.x / CPR;
@@ -50,33 +56,35 @@ struct EpiLinear {
             if (m >= M) continue;
             const int64_t o = (int64_t)m * ldo + n;
             f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
-            if (!OUT_BF16) {
+            if (!ACT_OUT) {
                 if (MODE == 1) v0 += rs[i];
-                if (MODE == 100) {
-                    if (v0[0] == 123456.789f) *(f32x4 *)((float *)out + o) = v0;  // experiment: main loop only
-                } else {
-                    *(f32x4 *)((float *)out + o) = v0;
-                }
+                *(f32x4 *)((float *)out + o) = v0;
             } else {
-                f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4);
+                f32x4 v1 = v0;
+                if (W == 8) v1 = *(const f32x4 *)(C + row * BN + col + 4);
                 if (MODE == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
-                        const f32x2 a = gelu_erf2(f32x2{v0[e], v0[e + 1]}), b = gelu_erf2(f32x2{v1[e], v1[e + 1]});
-                        v0[e] = a[0]; v0[e + 1] = a[1];
-                        v1[e] = b[0]; v1[e + 1] = b[1];
+                        const f32x2 a = gelu_erf2(f32x2{v0[e], v0[e + 1]});
+                        v0[e] = a[0];
+                        v0[e + 1] = a[1];
+                        if (W == 8) {
+                            const f32x2 b = gelu_erf2(f32x2{v1[e], v1[e + 1]});
+                            v1[e] = b[0];
+                            v1[e + 1] = b[1];
+                        }
                     }
                 }
-                *(bf16x8 *)((bf16 *)out + o) = cvt8(v0, v1);
+                store_chunk((OE *)out + o, v0, v1);
             }
         }
     }
 };
 
-template <class Cfg, bool SWAP, int KSTEPS, class ALoad, class Epi>
-static hipError_t launch_gemm_ks(const ALoad &al, const bf16 *w, int64_t ldw, int M, int N, int K, const Epi &epi,
+template <class Cfg, class E, bool SWAP, int KSTEPS, class ALoad, class Epi>
+static hipError_t launch_gemm_ks(const ALoad &al, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
                                  hipStream_t s) {
-    auto kern = gemm_kernel<Cfg, SWAP, KSTEPS, ALoad, Epi>;
+    auto kern = gemm_kernel<Cfg, E, SWAP, KSTEPS, ALoad, Epi>;
     static bool attr_set = false;  // benign race: idempotent
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -91,269 +99,49 @@ static hipError_t launch_gemm_ks(const ALoad &al, const bf16 *w, int64_t ldw, in
 
 // The K extents of ViT-S/B (D and 4D, and the patch embedding) get a compile-time step count, which
 // unlocks the two-step prefetch of gemm_mainloop; any other K runs the generic one-step pipeline.
-template <class Cfg, bool SWAP, class ALoad, class Epi>
-static hipError_t launch_gemm(const ALoad &al, const bf16 *w, int64_t ldw, int M, int N, int K, const Epi &epi,
+template <class Cfg, class E, bool SWAP, class ALoad, class Epi>
+static hipError_t launch_gemm(const ALoad &al, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
                               hipStream_t s) {
-    static const char *generic = getenv("OCM_GEMM_GENERIC");  // development switch
-    if (!generic) switch (K) {
-        case 384: return launch_gemm_ks<Cfg, SWAP, 6>(al, w, ldw, M, N, K, epi, s);
-        case 768: return launch_gemm_ks<Cfg, SWAP, 12>(al, w, ldw, M, N, K, epi, s);
-        case 1536: return launch_gemm_ks<Cfg, SWAP, 24>(al, w, ldw, M, N, K, epi, s);
-        case 3072: return launch_gemm_ks<Cfg, SWAP, 48>(al, w, ldw, M, N, K, epi, s);
+    if (K % Elem<E>::KROW) return hipErrorInvalidValue;
+    switch (K / Elem<E>::KROW) {
+        case 6: return launch_gemm_ks<Cfg, E, SWAP, 6>(al, w, ldw, M, N, K, epi, s);
+        case 12: return launch_gemm_ks<Cfg, E, SWAP, 12>(al, w, ldw, M, N, K, epi, s);
+        case 24: return launch_gemm_ks<Cfg, E, SWAP, 24>(al, w, ldw, M, N, K, epi, s);
+        case 48: return launch_gemm_ks<Cfg, E, SWAP, 48>(al, w, ldw, M, N, K, epi, s);
+        case 96: return launch_gemm_ks<Cfg, E, SWAP, 96>(al, w, ldw, M, N, K, epi, s);
         default: break;
     }
-    return launch_gemm_ks<Cfg, SWAP, 0>(al, w, ldw, M, N, K, epi, s);
+    return launch_gemm_ks<Cfg, E, SWAP, 0>(al, w, ldw, M, N, K, epi, s);
 }
 
-// ------------------------------------------------------------------------------------------
-// row-panel GEMM (gemm_panel.h) epilogues
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void panel_stage(const f32x16 (&acc)[2], float *slab, int lane) {
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) slab[acc_row32(e, h) * PANEL_CPAD + 32 * jn + r] = acc[jn][e];
-}
-
-template <int MODE>
-struct PanelEpiLinear {
-    const float *bias;
-    const float *resid;
-    void *out;
-    int M, N;
-    int64_t ldo;
-    __device__ __forceinline__ bool swap_for(int) const { return false; }
-    __device__ __forceinline__ void init(f32x16 (&acc)[2], bool, int n0, int lane) const {
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const float bv = bias[n0 + 32 * jn + (lane & 31)];  // lane = output column
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[jn][e] = bv;
-        }
-    }
-    __device__ __forceinline__ void stage(const f32x16 (&acc)[2], bool, float *slab, int lane) const {
-        panel_stage(acc, slab, lane);  // wave-private slab: LDS ops of one wave are ordered, no barrier
-    }
-    struct PartState {
-        f32x4 v0, v1;
-    };
-    // bf16 outputs: quarter p = rows 8p .. 8p+7, one 8-column chunk per lane.
-    // fp32 outputs: quarter p = rows 8p .. 8p+7 as two 4-column chunks per lane (rows 8p+{0..3}, 8p+{4..7}).
-    __device__ __forceinline__ void part_begin(PartState &st, int p, bool, const float *slab, int lane) const {
-        constexpr bool OUT_BF16 = (MODE == 2 || MODE == 3);
-        if (OUT_BF16) {
-            const int q = lane + 64 * p, row = q >> 3, col = (q & 7) * 8;
-            st.v0 = *(const f32x4 *)(slab + row * PANEL_CPAD + col);
-            st.v1 = *(const f32x4 *)(slab + row * PANEL_CPAD + col + 4);
-        } else {
-            const int q0 = lane + 64 * (2 * p), q1 = q0 + 64;
-            st.v0 = *(const f32x4 *)(slab + (q0 >> 4) * PANEL_CPAD + (q0 & 15) * 4);
-            st.v1 = *(const f32x4 *)(slab + (q1 >> 4) * PANEL_CPAD + (q1 & 15) * 4);
-        }
-    }
-    static constexpr bool kHasElem = (MODE == 2);
-    __device__ __forceinline__ void part_elem(PartState &st, int j) const {
-        if (MODE == 2 && (j & 1)) {  // a pair of elements after every second MFMA, on packed fp32
-            f32x4 &v = j < 4 ? st.v0 : st.v1;
-            const int e = (j & 3) - 1;
-            const f32x2 in = {v[e], v[e + 1]};
-            const f32x2 g = gelu_erf2(in);
-            v[e] = g[0];
-            v[e + 1] = g[1];
-        }
-    }
-    __device__ __forceinline__ void part_end(const PartState &st, int p, bool valid, bool, int mw, int n0,
-                                             int lane) const {
-        constexpr bool OUT_BF16 = (MODE == 2 || MODE == 3);
-        if (OUT_BF16) {
-            const int q = lane + 64 * p, row = q >> 3, col = (q & 7) * 8;
-            const int m = mw + row, n = n0 + col;
-            const bf16x8 o = cvt8(st.v0, st.v1);
-            if (valid && m < M) *(bf16x8 *)((bf16 *)out + (int64_t)m * ldo + n) = o;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int q = lane + 64 * (2 * p + i), row = q >> 4, col = (q & 15) * 4;
-                const int m = mw + row, n = n0 + col;
-                const bool ok = valid && m < M;
-                const int64_t o = (int64_t)(ok ? m : 0) * ldo + n;
-                f32x4 v = i ? st.v1 : st.v0;
-                if (MODE == 1 && ok) v += *(const f32x4 *)(resid + o);
-                if (ok && (MODE != 100 || v[0] == 123456.789f)) *(f32x4 *)((float *)out + o) = v;
-            }
-        }
-    }
-};
-
-struct PanelEpiQKV {
-    const float *bias;
-    bf16 *q, *k, *vt;
-    float *qkv32;
-    int M, ntok, npad, H, D, B;
-    __device__ __forceinline__ bool swap_for(int n0) const { return n0 >= 2 * D; }
-    __device__ __forceinline__ void init(f32x16 (&acc)[2], bool swapped, int n0, int lane) const {
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            if (!swapped) {
-                const float bv = bias[n0 + 32 * jn + (lane & 31)];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[jn][e] = bv;
-            } else {  // registers = output column (head-dim index)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[jn][e] = bias[n0 + 32 * jn + acc_row32(e, lane >> 5)];
-            }
-        }
-    }
-    __device__ __forceinline__ void stage(const f32x16 (&acc)[2], bool swapped, float *slab, int lane) const {
-        if (!swapped) {
-            panel_stage(acc, slab, lane);
-        } else {  // transposed accumulator (lane & 31 = token): staged as slab[d][token] (64 x 32)
-            const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-            for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) slab[(32 * jn + acc_row32(e, h)) * 32 + r] = acc[jn][e];
-        }
-    }
-    struct PartState {
-        const float *slab;
-    };
-    __device__ __forceinline__ void part_begin(PartState &st, int, bool, const float *slab, int) const { st.slab = slab; }
-    static constexpr bool kHasElem = false;
-    __device__ __forceinline__ void part_elem(PartState &, int) const {}
-    __device__ __forceinline__ void part_end(const PartState &st, int p, bool valid, bool swapped, int mw, int n0,
-                                             int lane) const {
-        const float *slab = st.slab;
-        const int which = n0 / D, head = (n0 - which * D) >> 6;  // a 64-wide tile is exactly one head of q, k or v
-        if (!swapped) {
-            const int qd = lane + 64 * p, row = qd >> 3, col = (qd & 7) * 8;
-            const int m = mw + row;
-            if (!valid || m >= M) return;
-            const int b = m / ntok, t = m - b * ntok;
-            const f32x4 v0 = *(const f32x4 *)(slab + row * PANEL_CPAD + col);
-            const f32x4 v1 = *(const f32x4 *)(slab + row * PANEL_CPAD + col + 4);
-            bf16 *dst = which ? k : q;
-            *(bf16x8 *)(dst + ((int64_t)(b * H + head) * npad + t) * 64 + col) = cvt8(v0, v1);
-            if (qkv32) {
-                float *o = qkv32 + ((((int64_t)which * B + b) * H + head) * ntok + t) * 64 + col;
-                *(f32x4 *)o = v0;
-                *(f32x4 *)(o + 4) = v1;
-            }
-        } else {  // V^T rows: lane & 31 = token (contiguous in vt), the two lane halves take even / odd d
-            const int r = lane & 31, h = lane >> 5, m = mw + r;
-            if (!valid || m >= M) return;
-            const int b = m / ntok, t = m - b * ntok;
-            bf16 *dst = vt + (int64_t)(b * H + head) * 64 * npad + t;
-            float *dst32 = qkv32 ? qkv32 + ((((int64_t)2 * B + b) * H + head) * ntok + t) * 64 : nullptr;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int d = 16 * p + 2 * i + h;
-                const float v = slab[d * 32 + r];
-                dst[(int64_t)d * npad] = (bf16)v;
-                if (dst32) dst32[d] = v;
-            }
-        }
-    }
-};
-
-static int device_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
-// The panel kernel serves K in {256, 384} (an even number of 64-deep steps whose A fragments fit
-// the register budget of 2 waves/SIMD) once there are enough rows to amortise the resident A panel.
-static bool panel_ok(int M, int N, int K) {
-    static int mode = -1;  // development switch: OCM_GEMM=panel enables the row-panel kernel (gemm_panel.h)
-    if (mode < 0) {
-        const char *e = getenv("OCM_GEMM");
-        mode = (e && !strcmp(e, "panel")) ? 1 : 0;  // the tiled kernel is faster on every shape measured so far
-    }
-    return mode && (K == 256 || K == 384) && N % 64 == 0 && M >= 512;
-}
-
-template <int KD, int NW, class Epi>
-static hipError_t launch_panel_kd(const bf16 *a, const bf16 *w, int M, int N, const Epi &epi, hipStream_t s) {
-    typedef PanelCfg<NW> PC;
-    auto kern = panel_gemm_kernel<KD, NW, Epi>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, PC::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const int rbs = (M + PC::BM - 1) / PC::BM, ntiles = N / PANEL_BN;
-    const int slots = device_cus() * (8 / NW);  // 8 waves per CU: one 8-wave or two 4-wave workgroups
-    int nsplit = (slots + rbs / 2) / rbs;       // row_blocks * nsplit ~ resident workgroup slots
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > ntiles) nsplit = ntiles;
-    kern<<<dim3(rbs * nsplit), dim3(PC::NT), PC::LDS_BYTES, s>>>(a, w, M, N, nsplit, epi);
-    return hipGetLastError();
-}
-
-static int panel_waves() {
-    static int nw = 0;
-    if (!nw) {
-        const char *e = getenv("OCM_PANEL_NW");  // development switch
-        nw = (e && atoi(e) == 4) ? 4 : 8;
-    }
-    return nw;
-}
-
-template <class Epi>
-static hipError_t launch_panel(const bf16 *a, const bf16 *w, int M, int N, int K, const Epi &epi, hipStream_t s) {
-    const bool w8 = panel_waves() == 8;
-    switch (K) {
-        case 256: return w8 ? launch_panel_kd<4, 8>(a, w, M, N, epi, s) : launch_panel_kd<4, 4>(a, w, M, N, epi, s);
-        case 384: return w8 ? launch_panel_kd<6, 8>(a, w, M, N, epi, s) : launch_panel_kd<6, 4>(a, w, M, N, epi, s);
-    }
-    return hipErrorInvalidValue;
-}
-
-typedef GemmCfg<128, 128, 2, 2> Cfg128x128;
-typedef GemmCfg<64, 128, 2, 2> Cfg64x128;
-typedef GemmCfg<64, 64, 2, 2> Cfg64x64;
-
-template <int MODE>
-static hipError_t launch_linear_mode(const bf16 *a, const bf16 *w, const float *bias, const float *resid, void *out,
-                                     int M, int N, int K, hipStream_t s) {
-    if (bias && panel_ok(M, N, K) && N >= 512) {  // wide projections (fc1): A panel resident in registers
-        PanelEpiLinear<MODE> pepi{bias, resid, out, M, N, N};
-        return launch_panel(a, w, M, N, K, pepi, s);
-    }
-    RowLoader al{a, K};
-    EpiLinear<MODE> epi{bias, resid, out, M, N, N};
+template <int MODE, class E>
+static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, const float *resid, void *out, int M,
+                                     int N, int K, hipStream_t s) {
+    RowLoader<E> al{a, K};
+    EpiLinear<MODE, E> epi{bias, resid, out, M, N, N};
     // Tile choice: fill >= 2 workgroups per CU (256 CUs) when the problem allows it.
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    const long t64 = (long)((M + 63) / 64) * ((N + 127) / 128);
-    static const char *force = getenv("OCM_TILE");
-    if (N % 128 == 0 && force && !strcmp(force, "128")) return launch_gemm<Cfg128x128, false>(al, w, K, M, N, K, epi, s);
-    if (N % 128 == 0 && force && !strcmp(force, "64")) return launch_gemm<Cfg64x128, false>(al, w, K, M, N, K, epi, s);
-    if (force && !strcmp(force, "6464")) return launch_gemm<Cfg64x64, false>(al, w, K, M, N, K, epi, s);
-    if (N % 128 == 0 && t128 >= 512) return launch_gemm<Cfg128x128, false>(al, w, K, M, N, K, epi, s);
-    if (N % 128 == 0 && t64 >= 256) return launch_gemm<Cfg64x128, false>(al, w, K, M, N, K, epi, s);
-    if (N % 128 == 0 && M > 64) return launch_gemm<Cfg64x128, false>(al, w, K, M, N, K, epi, s);
-    return launch_gemm<Cfg64x64, false>(al, w, K, M, N, K, epi, s);
+    if (N % 128 == 0 && t128 >= 512) return launch_gemm<Cfg128x128, E, false>(al, w, K, M, N, K, epi, s);
+    if (N % 128 == 0 && M > 64) return launch_gemm<Cfg64x128, E, false>(al, w, K, M, N, K, epi, s);
+    return launch_gemm<Cfg64x64, E, false>(al, w, K, M, N, K, epi, s);
 }
 
-hipError_t launch_linear(const bf16 *a, const bf16 *w, const float *bias, const float *resid, void *out, int M,
-                         int N, int K, int epilogue, hipStream_t s) {
+template <class E>
+static hipError_t launch_linear_e(const E *a, const E *w, const float *bias, const float *resid, void *out, int M, int N,
+                                  int K, int epilogue, hipStream_t s) {
     switch (epilogue) {
-        case 0: return launch_linear_mode<0>(a, w, bias, resid, out, M, N, K, s);
-        case 1: return launch_linear_mode<1>(a, w, bias, resid, out, M, N, K, s);
-        case 2: return launch_linear_mode<2>(a, w, bias, resid, out, M, N, K, s);
-        case 3: return launch_linear_mode<3>(a, w, bias, resid, out, M, N, K, s);
-        case 100: return launch_linear_mode<100>(a, w, bias, resid, out, M, N, K, s);
+        case 0: return launch_linear_mode<0, E>(a, w, bias, resid, out, M, N, K, s);
+        case 1: return launch_linear_mode<1, E>(a, w, bias, resid, out, M, N, K, s);
+        case 2: return launch_linear_mode<2, E>(a, w, bias, resid, out, M, N, K, s);
+        case 3: return launch_linear_mode<3, E>(a, w, bias, resid, out, M, N, K, s);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_linear(int prec, const void *a, const void *w, const float *bias, const float *resid, void *out, int M,
+                         int N, int K, int epilogue, hipStream_t s) {
+    if (prec) return launch_linear_e<float>((const float *)a, (const float *)w, bias, resid, out, M, N, K, epilogue, s);
+    return launch_linear_e<bf16>((const bf16 *)a, (const bf16 *)w, bias, resid, out, M, N, K, epilogue, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -364,9 +152,10 @@ hipError_t launch_linear(const bf16 *a, const bf16 *w, const float *bias, const 
 // column tiles inside [2D, 3D) run the main loop with the MFMA operands swapped, so the
 // accumulator is transposed (lane = token) and V is written as V^T  vt[(b*H + head)][d][t]
 // with the token index contiguous — the layout the P·V MFMA consumes — at full store width.
+template <class E>
 struct EpiQK {
     const float *bias;
-    bf16 *q, *k;
+    E *q, *k;
     float *qkv32;  // optional (3,B,H,N,64) fp32, or nullptr
     int M, ntok, npad, H, D, B;
     // C is [BM][BN] (rows = tokens). One lane moves 8 consecutive head-dim columns of one token.
@@ -382,8 +171,13 @@ struct EpiQK {
             const int b = m / ntok, t = m - b * ntok;
             const f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
             const f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4);
-            bf16 *dst = which ? k : q;
-            *(bf16x8 *)(dst + ((int64_t)(b * H + head) * npad + t) * 64 + d) = cvt8(v0, v1);
+            E *dst = (which ? k : q) + ((int64_t)(b * H + head) * npad + t) * 64 + d;
+            if (sizeof(E) == 2) {
+                store_chunk(dst, v0, v1);
+            } else {
+                store_chunk(dst, v0, v0);
+                store_chunk(dst + 4, v1, v1);
+            }
             if (qkv32) {
                 float *o = qkv32 + ((((int64_t)which * B + b) * H + head) * ntok + t) * 64 + d;
                 *(f32x4 *)o = v0;
@@ -393,9 +187,10 @@ struct EpiQK {
     }
 };
 
+template <class E>
 struct EpiVt {
     const float *bias;
-    bf16 *vt;
+    E *vt;
     float *qkv32;
     int M, ntok, npad, H, D, B;
     // C is the TRANSPOSED tile [BN][BM] (rows = features n, columns = tokens m). Consecutive lanes
@@ -412,15 +207,15 @@ struct EpiVt {
         for (int row = threadIdx.x / BM; row < BN; row += NT / BM) {
             const int rem = rem0 + row, head = rem >> 6, d = rem & 63;
             const float v = C[row * BM + col];
-            vt[((int64_t)(b * H + head) * 64 + d) * npad + t] = (bf16)v;
+            vt[((int64_t)(b * H + head) * 64 + d) * npad + t] = (E)v;
             if (qkv32) qkv32[((((int64_t)2 * B + b) * H + head) * ntok + t) * 64 + d] = v;
         }
     }
 };
 
-template <class Cfg, int KSTEPS>
-__global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader al, const bf16 *__restrict__ W, int M, int D,
-                                                      EpiQK eqk, EpiVt ev) {
+template <class Cfg, class E, int KSTEPS>
+__global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader<E> al, const E *__restrict__ W, int M, int D,
+                                                      EpiQK<E> eqk, EpiVt<E> ev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = 3 * D, K = D;
     const int tiles_n = N / Cfg::BN;  // D % BN == 0 is checked by the launcher
@@ -429,20 +224,20 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader al, const bf16 *
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
     if (n0 < 2 * D) {  // workgroup-uniform
-        gemm_mainloop<Cfg, false, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
+        gemm_mainloop<Cfg, E, false, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
         stage_acc<Cfg, false>(acc, smem);
         eqk.template run<Cfg>((const float *)smem, m0, n0);
     } else {
-        gemm_mainloop<Cfg, true, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
+        gemm_mainloop<Cfg, E, true, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
         stage_acc<Cfg, true>(acc, smem);
         ev.template run<Cfg>((const float *)smem, m0, n0);
     }
 }
 
-template <class Cfg, int KSTEPS>
-static hipError_t launch_qkv_ks(const RowLoader &al, const bf16 *w, int M, int D, const EpiQK &eqk, const EpiVt &ev,
-                                hipStream_t s) {
-    auto kern = qkv_kernel<Cfg, KSTEPS>;
+template <class Cfg, class E, int KSTEPS>
+static hipError_t launch_qkv_ks(const RowLoader<E> &al, const E *w, int M, int D, const EpiQK<E> &eqk,
+                                const EpiVt<E> &ev, hipStream_t s) {
+    auto kern = qkv_kernel<Cfg, E, KSTEPS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -455,30 +250,38 @@ static hipError_t launch_qkv_ks(const RowLoader &al, const bf16 *w, int M, int D
     return hipGetLastError();
 }
 
-template <class Cfg>
-static hipError_t launch_qkv_cfg(const RowLoader &al, const bf16 *w, int M, int D, const EpiQK &eqk, const EpiVt &ev,
-                                 hipStream_t s) {
-    static const char *generic = getenv("OCM_GEMM_GENERIC");
-    if (!generic && D == 384) return launch_qkv_ks<Cfg, 6>(al, w, M, D, eqk, ev, s);
-    if (!generic && D == 768) return launch_qkv_ks<Cfg, 12>(al, w, M, D, eqk, ev, s);
-    return launch_qkv_ks<Cfg, 0>(al, w, M, D, eqk, ev, s);
+template <class Cfg, class E>
+static hipError_t launch_qkv_cfg(const RowLoader<E> &al, const E *w, int M, int D, const EpiQK<E> &eqk,
+                                 const EpiVt<E> &ev, hipStream_t s) {
+    switch (D / Elem<E>::KROW) {
+        case 6: return launch_qkv_ks<Cfg, E, 6>(al, w, M, D, eqk, ev, s);
+        case 12: return launch_qkv_ks<Cfg, E, 12>(al, w, M, D, eqk, ev, s);
+        case 24: return launch_qkv_ks<Cfg, E, 24>(al, w, M, D, eqk, ev, s);
+        default: break;
+    }
+    return launch_qkv_ks<Cfg, E, 0>(al, w, M, D, eqk, ev, s);
 }
 
-hipError_t launch_qkv(const bf16 *a, const bf16 *w, const float *bias, bf16 *q, bf16 *k, bf16 *vt, float *qkv_f32,
-                      int batch, int n_tokens, int n_pad, int heads, hipStream_t s) {
+template <class E>
+static hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E *vt, float *qkv_f32, int batch,
+                               int n_tokens, int n_pad, int heads, hipStream_t s) {
     const int D = heads * 64, M = batch * n_tokens;
-    static const char *qkv_panel = getenv("OCM_QKV_PANEL");  // development switch (the panel qkv epilogue spills)
-    if (qkv_panel && panel_ok(M, 3 * D, D)) {
-        PanelEpiQKV pepi{bias, q, k, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
-        return launch_panel(a, w, M, 3 * D, D, pepi, s);
-    }
-    RowLoader al{a, D};
-    EpiQK eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
-    EpiVt ev{bias, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
+    RowLoader<E> al{a, D};
+    EpiQK<E> eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
+    EpiVt<E> ev{bias, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
     const long t128 = (long)((M + 127) / 128) * (3 * D / 128);
-    if (D % 128 == 0 && t128 >= 512) return launch_qkv_cfg<Cfg128x128>(al, w, M, D, eqk, ev, s);
-    if (D % 128 == 0) return launch_qkv_cfg<Cfg64x128>(al, w, M, D, eqk, ev, s);
-    return launch_qkv_cfg<Cfg64x64>(al, w, M, D, eqk, ev, s);
+    if (D % 128 == 0 && t128 >= 512) return launch_qkv_cfg<Cfg128x128, E>(al, w, M, D, eqk, ev, s);
+    if (D % 128 == 0) return launch_qkv_cfg<Cfg64x128, E>(al, w, M, D, eqk, ev, s);
+    return launch_qkv_cfg<Cfg64x64, E>(al, w, M, D, eqk, ev, s);
+}
+
+hipError_t launch_qkv(int prec, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
+                      float *qkv_f32, int batch, int n_tokens, int n_pad, int heads, hipStream_t s) {
+    if (prec)
+        return launch_qkv_e<float>((const float *)a, (const float *)w, bias, (float *)q, (float *)k, (float *)vt, qkv_f32,
+                                   batch, n_tokens, n_pad, heads, s);
+    return launch_qkv_e<bf16>((const bf16 *)a, (const bf16 *)w, bias, (bf16 *)q, (bf16 *)k, (bf16 *)vt, qkv_f32, batch,
+                              n_tokens, n_pad, heads, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -486,9 +289,10 @@ hipError_t launch_qkv(const bf16 *a, const bf16 *w, const float *bias, bf16 *q, 
 // ------------------------------------------------------------------------------------------
 // Row m = b*P + py*wp + px is the p x p patch at (py, px) of tile b (row-major flatten, :131);
 // column k = c*p*p + dy*p + dx indexes conv weight (D, C, p, p) flattened (:127). A 16-B LDS
-// chunk is 8 consecutive dx of one (c, dy): two float4 loads from one image row, converted to
-// bf16 on the way into LDS. Consecutive threads walk consecutive chunks of a row, so a wave
-// reads whole 32-B..64-B row segments of neighbouring patches (coalesced along x).
+// chunk is 8 (bf16) or 4 (fp32) consecutive dx of one (c, dy): float4 loads from one image row,
+// converted to bf16 on the way into LDS in the bf16 path. Consecutive threads walk consecutive
+// chunks of a row, so a wave reads whole row segments of neighbouring patches (coalesced along x).
+template <class E>
 struct PatchLoader {
     const float *image;
     int64_t sb, sc, sy;
@@ -514,13 +318,19 @@ struct PatchLoader {
         const float *ptr = h + (int64_t)c * sc + (int64_t)dy * sy + dx;
         Raw r;
         r.lo = *(const f32x4 *)ptr;
-        r.hi = *(const f32x4 *)(ptr + 4);
+        r.hi = r.lo;
+        if (sizeof(E) == 2) r.hi = *(const f32x4 *)(ptr + 4);
         return r;
     }
-    __device__ __forceinline__ static bf16x8 finish(const Raw &r) { return cvt8(r.lo, r.hi); }
+    __device__ __forceinline__ static typename Elem<E>::Chunk finish(const Raw &r) {
+        if constexpr (sizeof(E) == 2)
+            return cvt8(r.lo, r.hi);
+        else
+            return r.lo;
+    }
 };
 
-// x[b][1 + pi][n] = acc + bias[n] + pos[1 + pi][n]   (prepare_tokens :200-207, patch rows)
+// x[b][1 + pi][n] = acc + pos[1 + pi][n]   (prepare_tokens :200-207, patch rows; bias is in acc)
 struct EpiPatch {
     const float *bias, *pos;
     float *x;
@@ -540,18 +350,18 @@ struct EpiPatch {
     }
 };
 
-hipError_t launch_patch_embed(const PatchArgs &pa, const bf16 *w, const float *bias, const float *pos, float *x,
-                              int dim, hipStream_t s) {
+template <class E>
+static hipError_t launch_patch_e(const PatchArgs &pa, const E *w, const float *bias, const float *pos, float *x, int dim,
+                                 hipStream_t s) {
     const int P = pa.hp * pa.wp, M = pa.batch * P, K = pa.chans * pa.p * pa.p;
-    PatchLoader al{pa.image, pa.sb, pa.sc, pa.sy, pa.origins, P, pa.wp, pa.p, pa.p * pa.p};
+    PatchLoader<E> al{pa.image, pa.sb, pa.sc, pa.sy, pa.origins, P, pa.wp, pa.p, pa.p * pa.p};
     EpiPatch epi{bias, pos, x, M, P, P + 1, dim};
-    if (dim % 128 == 0 && M > 64) return launch_gemm<Cfg64x128, false>(al, w, K, M, dim, K, epi, s);
-    return launch_gemm<Cfg64x64, false>(al, w, K, M, dim, K, epi, s);
+    if (dim % 128 == 0 && M > 64) return launch_gemm<Cfg64x128, E, false>(al, w, K, M, dim, K, epi, s);
+    return launch_gemm<Cfg64x64, E, false>(al, w, K, M, dim, K, epi, s);
 }
 
-#ifdef PANEL_STAMP
-extern "C" int ocm_debug_panel_stamps(unsigned long long *out, int n) {
-    if (n > 512) n = 512;
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_panel_stamps), (size_t)n * 8, 0, hipMemcpyDeviceToHost);
+hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, const float *bias, const float *pos,
+                              float *x, int dim, hipStream_t s) {
+    if (prec) return launch_patch_e<float>(pa, (const float *)w, bias, pos, x, dim, s);
+    return launch_patch_e<bf16>(pa, (const bf16 *)w, bias, pos, x, dim, s);
 }
-#endif

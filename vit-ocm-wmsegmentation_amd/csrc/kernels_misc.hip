@@ -177,6 +177,22 @@ __global__ __launch_bounds__(256) void fold_cast_kernel(const float *__restrict_
     dst[i] = (bf16)s;
 }
 
+__global__ __launch_bounds__(256) void fold_f32_kernel(const float *__restrict__ src, float *__restrict__ dst, int D,
+                                                       int C, int pp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D * pp) return;
+    const int d = i / pp, k = i - d * pp;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += src[((size_t)d * C + c) * pp + k];
+    dst[i] = s;
+}
+
+hipError_t launch_fold_f32(const float *src, float *dst, int D, int C, int pp, hipStream_t s) {
+    const int n = D * pp;
+    fold_f32_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(src, dst, D, C, pp);
+    return hipGetLastError();
+}
+
 hipError_t launch_fold_cast_bf16(const float *src, bf16 *dst, int D, int C, int pp, hipStream_t s) {
     const int n = D * pp;
     fold_cast_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(src, dst, D, C, pp);

@@ -9,13 +9,16 @@ hipError_t launch_layernorm(const float *x, const float *gamma, const float *bet
 hipError_t launch_cast_bf16(const float *src, bf16 *dst, size_t count, hipStream_t s);
 // sum over the channel axis of a (D, C, p, p) conv weight -> bf16 (D, p*p): grayscale fold.
 hipError_t launch_fold_cast_bf16(const float *src, bf16 *dst, int D, int C, int pp, hipStream_t s);
+hipError_t launch_fold_f32(const float *src, float *dst, int D, int C, int pp, hipStream_t s);
 hipError_t launch_cls_rows(const float *cls, const float *pos, float *x, int batch, int n_tokens, int dim,
                            hipStream_t s);
 
+// `prec` selects the operand element type of the contraction kernels: 0 = bf16 (OCM_PREC_BF16),
+// 1 = fp32 (OCM_PREC_FP32). Activation buffers (a, q, k, vt, ctx, ...) and weights are of that type.
 // ---- kernels_gemm.hip
-hipError_t launch_linear(const bf16 *a, const bf16 *w, const float *bias, const float *resid, void *out, int M,
+hipError_t launch_linear(int prec, const void *a, const void *w, const float *bias, const float *resid, void *out, int M,
                          int N, int K, int epilogue, hipStream_t s);
-hipError_t launch_qkv(const bf16 *a, const bf16 *w, const float *bias, bf16 *q, bf16 *k, bf16 *vt,
+hipError_t launch_qkv(int prec, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
                       float *qkv_f32, int batch, int n_tokens, int n_pad, int heads, hipStream_t s);
 struct PatchArgs {
     const float *image;
@@ -23,16 +26,16 @@ struct PatchArgs {
     const int32_t *origins;
     int batch, hp, wp, p, chans;  // hp x wp patches per tile
 };
-hipError_t launch_patch_embed(const PatchArgs &pa, const bf16 *w, const float *bias, const float *pos, float *x,
-                              int dim, hipStream_t s);
+hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, const float *bias, const float *pos,
+                              float *x, int dim, hipStream_t s);
 
 // ---- kernels_attn.hip
-hipError_t launch_attention(const bf16 *q, const bf16 *k, const bf16 *vt, bf16 *ctx, float *lse2, int batch,
+hipError_t launch_attention(int prec, const void *q, const void *k, const void *vt, void *ctx, float *lse2, int batch,
                             int n_tokens, int n_pad, int heads, float scale, hipStream_t s);
-hipError_t launch_attention_probs(const bf16 *q, const bf16 *k, const float *lse2, float *attn, int batch,
+hipError_t launch_attention_probs(int prec, const void *q, const void *k, const float *lse2, float *attn, int batch,
                                   int n_tokens, int n_pad, int heads, float scale, hipStream_t s);
-hipError_t launch_attention_rows(const bf16 *q, const bf16 *k, const int32_t *query_rows, int n_rows, float *rows,
-                                 int batch, int n_tokens, int n_pad, int heads, float scale, hipStream_t s);
+hipError_t launch_attention_rows(int prec, const void *q, const void *k, const int32_t *query_rows, int n_rows,
+                                 float *rows, int batch, int n_tokens, int n_pad, int heads, float scale, hipStream_t s);
 hipError_t launch_attention_map(const float *attn, float *maps, int b, int heads, int n_tokens, int query, int hf,
                                 int wf, int p, hipStream_t s);
 

@@ -91,10 +91,10 @@ class Mlp(nn.Module):
         with torch.cuda.device(x32.device):
             a = _cast_bf16(x32)
             h = torch.empty((rows, hid), dtype=torch.bfloat16, device=x32.device)
-            _lib.check(lib.ocm_op_linear(_p(a), _p(self._w[0].get(self.fc1.weight)), _p(_bias_or_zeros(self.fc1)), None,
+            _lib.check(lib.ocm_op_linear(0, _p(a), _p(self._w[0].get(self.fc1.weight)), _p(_bias_or_zeros(self.fc1)), None,
                                          _p(h), rows, hid, shape[-1], _lib.OCM_EPI_BIAS_GELU_BF16, _stream()))
             y = torch.empty((rows, out_f), dtype=torch.float32, device=x32.device)
-            _lib.check(lib.ocm_op_linear(_p(h), _p(self._w[1].get(self.fc2.weight)), _p(_bias_or_zeros(self.fc2)), None,
+            _lib.check(lib.ocm_op_linear(0, _p(h), _p(self._w[1].get(self.fc2.weight)), _p(_bias_or_zeros(self.fc2)), None,
                                          _p(y), rows, out_f, hid, _lib.OCM_EPI_BIAS_F32, _stream()))
         return y.reshape(*shape[:-1], out_f)
 
@@ -127,15 +127,15 @@ class Attention(nn.Module):
             k = torch.empty_like(q)
             vt = torch.empty((B * H, 64, npad), dtype=torch.bfloat16, device=dev)
             qkv = torch.empty((3, B, H, N, 64), dtype=torch.float32, device=dev)
-            _lib.check(lib.ocm_op_qkv_proj(_p(a), _p(self._w[0].get(self.qkv.weight)), _p(_bias_or_zeros(self.qkv)),
+            _lib.check(lib.ocm_op_qkv_proj(0, _p(a), _p(self._w[0].get(self.qkv.weight)), _p(_bias_or_zeros(self.qkv)),
                                            _p(q), _p(k), _p(vt), _p(qkv), B, N, H, _stream()))
             ctx = torch.empty((B * N, Cd), dtype=torch.bfloat16, device=dev)
             lse = torch.empty((B * H, N), dtype=torch.float32, device=dev)
-            _lib.check(lib.ocm_op_attention(_p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, float(self.scale), _stream()))
+            _lib.check(lib.ocm_op_attention(0, _p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, float(self.scale), _stream()))
             attn = torch.empty((B, H, N, N), dtype=torch.float32, device=dev)
-            _lib.check(lib.ocm_op_attention_probs(_p(q), _p(k), _p(lse), _p(attn), B, N, H, float(self.scale), _stream()))
+            _lib.check(lib.ocm_op_attention_probs(0, _p(q), _p(k), _p(lse), _p(attn), B, N, H, float(self.scale), _stream()))
             y = torch.empty((B * N, Cd), dtype=torch.float32, device=dev)
-            _lib.check(lib.ocm_op_linear(_p(ctx), _p(self._w[1].get(self.proj.weight)), _p(_bias_or_zeros(self.proj)),
+            _lib.check(lib.ocm_op_linear(0, _p(ctx), _p(self._w[1].get(self.proj.weight)), _p(_bias_or_zeros(self.proj)),
                                          None, _p(y), B * N, Cd, Cd, _lib.OCM_EPI_BIAS_F32, _stream()))
         return y.reshape(B, N, Cd), attn, qkv
 
@@ -227,6 +227,7 @@ class VisionTransformer(nn.Module):
         self.__dict__["_engines"] = {}
         self.__dict__["_pos_cache"] = {}
         self.__dict__["_gray_fold"] = False
+        self.__dict__["_precision"] = "bf16"
         for i, blk in enumerate(self.blocks):
             blk.__dict__["_owner"] = (self,)
             blk.__dict__["_index"] = i
@@ -258,6 +259,20 @@ class VisionTransformer(nn.Module):
         self.__dict__["_engines"] = {}
         return self
 
+    def set_precision(self, precision):
+        """Arithmetic of the contraction kernels (residual stream, LayerNorm, softmax and accumulators
+        are fp32 in both):
+          "bf16" (default) bf16 MFMA operands — the fast path; attention maps within 1e-3 of the fp32
+                           reference on well-conditioned weights
+          "fp32"           fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products, 1/16 the matrix
+                           rate): reference-grade maps for weights / inputs that amplify bf16 rounding"""
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
+        if precision != self._precision:
+            self.__dict__["_precision"] = precision
+            self.__dict__["_engines"] = {}
+        return self
+
     def _named_engine_params(self):
         skip = ("pos_embed", "head.", "mask_token")
         return [(n, p) for n, p in self.named_parameters() if not n.startswith(skip)]
@@ -276,7 +291,7 @@ class VisionTransformer(nn.Module):
         hy = dict(self._hyper)
         if self._gray_fold:
             hy["in_chans"] = 1
-        eng = ent[0] if ent is not None else Engine(device=device, **hy)
+        eng = ent[0] if ent is not None else Engine(device=device, precision=_lib.PRECISIONS[self._precision], **hy)
         have = set()
         for name, p in named:
             eng.set_param(name, p)
