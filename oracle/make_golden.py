@@ -115,9 +115,56 @@ def run_case(name, case):
           f"-> {os.path.relpath(path, ROOT)} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def run_helpers():
+    """Pin the three caller-side helpers on the path with the reference's OWN functions (extracted from
+    utils.py / sw_processing.py by oracle/ref_extract.py, because those modules import cv2 etc.):
+      compute_attention  utils.py:229-235      sliding_window  sw_processing.py:151-163
+      concat_crops / blend_images_*  sw_processing.py:113-149  (the stitcher)"""
+    from PIL import Image
+
+    from oracle.ref_extract import load_functions
+    ref_u = load_functions(os.path.join(REF, "utils.py"), ["compute_attention"])
+    ref_s = load_functions(os.path.join(REF, "sw_processing.py"),
+                           ["sliding_window", "concat_crops", "blend_images_vertically", "blend_images_horizontally"])
+    # the extracted functions call each other through their module globals
+    ref_s["concat_crops"].__globals__.update(ref_s)
+    out = {}
+    # compute_attention: B=2, H=3, 5x7 patches, p=8; two query rows
+    g = torch.Generator().manual_seed(21)
+    attn = torch.rand(2, 3, 36, 36, generator=g)
+    out["ca_attn"] = attn.numpy()
+    for query in (0, 9):
+        maps, nh = ref_u["compute_attention"]([attn], query, 5, 7, 8)
+        omaps, onh = O.compute_attention([attn], query, 5, 7, 8)
+        assert nh == onh and np.array_equal(maps, omaps)
+        out[f"ca_maps_q{query}"] = maps
+    # sliding_window: window origins recovered from crops of an index image (pixel value = y * W + x)
+    for size in (640, 1152):
+        idx = np.arange(size * size, dtype=np.int32).reshape(size, size)
+        crops = ref_s["sliding_window"](Image.fromarray(idx, mode="I"), 128, 384)
+        origins = np.array([[int(c[0, 0]) // size, int(c[0, 0]) % size] for c in crops], dtype=np.int32)
+        assert all(c.shape == (384, 384) for c in crops)
+        assert [tuple(o) for o in origins.tolist()] == O.sliding_window_origins(size, size, 128)
+        out[f"sw_origins_{size}"] = origins
+    # stitcher: 3x3 and 2x2 grids of float32 crops
+    for n, seed in ((3, 5), (2, 6)):
+        rng = np.random.default_rng(seed)
+        crops = [rng.random((384, 384), dtype=np.float32) * 255 for _ in range(n * n)]
+        stitched = ref_s["concat_crops"](crops, 128, 384)
+        ostitched = O.concat_crops(np.stack(crops), 128, 384)
+        assert stitched.shape == (384 + (n - 1) * 128,) * 2 and np.array_equal(stitched, ostitched)
+        out[f"stitch_{n}_seed"] = np.int64(seed)
+        out[f"stitch_{n}"] = stitched.astype(np.float32)
+    path = os.path.join(GOLD, "helpers.npz")
+    np.savez_compressed(path, **out)
+    print(f"helpers            compute_attention / sliding_window / concat_crops pinned -> {os.path.relpath(path, ROOT)} "
+          f"({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    run_helpers()
     for name, case in CASES.items():
         run_case(name, case)
 

@@ -146,7 +146,8 @@ def get_intermediate_layers(sd, cfg, x, n=1):
 
 
 def compute_attention(attentions, query, w_featmap, h_featmap, patch_size):
-    """utils.py:229-235 (the module itself needs cv2/skimage, absent here: restated from its text)."""
+    """utils.py:229-235. Pinned: oracle/make_golden.py runs the reference's own function (extracted from the file,
+    whose module import needs cv2/skimage) on the same inputs -> tests/golden/helpers.npz."""
     a = attentions[0]
     nh = a.shape[1]
     a = a[0, :, query, 1:].reshape(nh, -1)
@@ -172,6 +173,36 @@ def sliding_window_crops(image_chw, stride, window):
     array slice for in-bounds boxes)."""
     _, H, W = image_chw.shape
     return torch.stack([image_chw[:, y:y + window, x:x + window] for y, x in sliding_window_origins(H, W, stride)])
+
+
+def blend_overlap(a, b, axis):
+    """sw_processing.py:136-149: linear ramp np.linspace(1, 0, n) over the overlap along `axis`
+    (weights are float64 there; the sum is cast back to the crops' dtype on assignment)."""
+    n = a.shape[axis]
+    w = np.linspace(1, 0, n)
+    w = w[:, None] if axis == 0 else w[None, :]
+    return (a * w + b * (1 - w)).astype(a.dtype)
+
+
+def concat_crops(crops, stride, window):
+    """sw_processing.py:113-134: sequential left-to-right then top-to-bottom stitching of the n x n
+    row-major window grid, each new crop blended over the `window - stride` overlap with the
+    image accumulated so far."""
+    n = int(np.sqrt(len(crops)))
+    step = window - stride
+    vertical = None
+    for i in range(n):
+        horizontal = crops[i * n]
+        for j in range(1, n):
+            right = crops[i * n + j]
+            overlap = blend_overlap(horizontal[:, -step:], right[:, :-stride], axis=1)
+            horizontal = np.concatenate((horizontal[:, :-step], overlap, right[:, -stride:]), axis=1)
+        if i == 0:
+            vertical = horizontal
+        else:
+            top = blend_overlap(vertical[-step:, :], horizontal[:-stride, :], axis=0)
+            vertical = np.concatenate((vertical[:-step, :], top, horizontal[-stride:, :]), axis=0)
+    return vertical
 
 
 def tile_head_mean_maps(sd, cfg, tiles, patch_size):

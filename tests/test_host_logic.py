@@ -65,6 +65,13 @@ def test_sliding_window_index_math_bit_exact(size, stride):
     assert sw_processing.window_count(size, stride) == len(range(0, size - 2 * stride, stride))
 
 
+def test_sliding_window_origins_match_reference_golden():
+    from tests.helpers import load_golden
+    gold = load_golden("helpers")  # origins produced by the reference's own sliding_window
+    for size in (640, 1152):
+        assert np.array_equal(sw_processing.sliding_window_origins(size, size, 128), gold[f"sw_origins_{size}"])
+
+
 def test_sliding_window_rectangular():
     ref = O.sliding_window_origins(768, 1152, 128)
     got = sw_processing.sliding_window_origins(768, 1152, 128)

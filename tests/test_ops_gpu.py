@@ -4,6 +4,7 @@ operands. Runs on a real MI355X only."""
 import ctypes as C
 import math
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -158,6 +159,17 @@ def test_attention(lib, dev, B, N, H, sharp):
     _ok(lib, lib.ocm_op_attention_rows(0, _p(qp), _p(kp), _p(rows_idx), 3, _p(rows), B, N, H, scale, _s()))
     ref_rows = pref.reshape(B, H, N, N)[:, :, rows_idx.long(), 1:]
     assert (rows - ref_rows).abs().max().item() < 2e-5
+
+
+def test_attention_map_matches_reference_golden(lib, dev):
+    """ocm_op_attention_map against the output of the reference's own compute_attention (helpers.npz)."""
+    from tests.helpers import load_golden
+    gold = load_golden("helpers")
+    attn = torch.from_numpy(gold["ca_attn"]).to(dev)
+    for query in (0, 9):
+        maps = torch.empty((3, 5 * 8, 7 * 8), device=dev)
+        _ok(lib, lib.ocm_op_attention_map(_p(attn), _p(maps), 0, 3, 36, query, 5, 7, 8, _s()))
+        assert np.array_equal(maps.cpu().numpy(), gold[f"ca_maps_q{query}"])
 
 
 def test_attention_map(lib, dev):

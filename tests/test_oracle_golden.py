@@ -66,3 +66,19 @@ def test_sliding_window_origins_restatement():
     assert len(o) == 900 and o[-1] == (3712, 3712) and o[-1][0] + 384 == 4096
     assert O.sliding_window_origins(256, 256, 128) == []  # size - 2*stride <= 0: no window
     assert O.sliding_window_origins(384, 384, 128) == [(0, 0)]
+
+
+def test_helpers_match_reference_golden():
+    """compute_attention / sliding_window / concat_crops: the oracle against outputs of the REFERENCE's own
+    functions (tests/golden/helpers.npz, written by oracle/make_golden.py::run_helpers)."""
+    gold = load_golden("helpers")
+    attn = torch.from_numpy(gold["ca_attn"])
+    for query in (0, 9):
+        maps, nh = O.compute_attention([attn], query, 5, 7, 8)
+        assert nh == 3 and np.array_equal(maps, gold[f"ca_maps_q{query}"])
+    for size in (640, 1152):
+        assert [tuple(o) for o in gold[f"sw_origins_{size}"].tolist()] == O.sliding_window_origins(size, size, 128)
+    for n in (3, 2):
+        rng = np.random.default_rng(int(gold[f"stitch_{n}_seed"]))
+        crops = np.stack([rng.random((384, 384), dtype=np.float32) * 255 for _ in range(n * n)])
+        assert np.array_equal(O.concat_crops(crops, 128, 384), gold[f"stitch_{n}"])
