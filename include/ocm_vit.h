@@ -230,6 +230,29 @@ enum {
 int ocm_prof_begin(uint32_t class_mask, int32_t max_launches);
 int ocm_prof_end(double *ms_per_class /*[OCM_K_COUNT]*/, int64_t *launches_per_class /*[OCM_K_COUNT]*/);
 
+/* ---- sliding-window post-processing on device (SURVEY §8-f "next" rows 1-2; sw_processing.py) ---- */
+/* :245 + :253-254 — rows (T,H,n_rows,P) CLS-row maps (row 0 used) -> maps (T,P):
+ * head mean (sequential fp32, as np.mean(axis=0)) then per-window (v - min) / (max - min) * 255. */
+int ocm_op_tile_postprocess(const float *rows, float *maps, int32_t tiles, int32_t heads, int32_t n_rows,
+                            int32_t pixels, void *stream);
+/* :255-257 — cv2.resize(INTER_LINEAR) x`scale` of (T,h,w) float32 maps: half-pixel centres, replicate
+ * border, fp32 (cv2 is an un-vendored dependency: parity unpinned). */
+int ocm_op_bilinear_upsample(const float *src, float *dst, int32_t tiles, int32_t h, int32_t w, int32_t scale,
+                             void *stream);
+/* concat_crops :113-149 — n x n row-major float32 windows (n*n, window, window) -> (S,S),
+ * S = window + (n-1)*stride; ramp = np.linspace(1, 0, window - stride) as float64 on device.
+ * Bit-exact with the reference's sequential stitcher. stride < window <= 3*stride. */
+int ocm_op_stitch(const float *crops, float *out, const double *ramp, int32_t n, int32_t window,
+                  int32_t stride, void *stream);
+/* threshold() :43-48 — min_max_normalize -> *255 -> astype(uint8) and the 256-bin histogram of the result.
+ * scratch: >= 2048 bytes of device memory. */
+int ocm_op_normalize_u8(const float *img, int64_t count, void *scratch, uint8_t *out, uint64_t *hist256,
+                        void *stream);
+/* cv2.threshold(img, 0, 255, THRESH_BINARY + THRESH_OTSU) :62 — host part: Otsu level of a histogram
+ * (restates OpenCV's getThreshVal_Otsu_8u; parity unpinned), and the binary mask on device. */
+int32_t ocm_otsu_threshold(const uint64_t *hist256_host, int64_t count);
+int ocm_op_threshold_u8(const uint8_t *img, uint8_t *mask, int64_t count, int32_t thresh, void *stream);
+
 /* ---- sliding-window index math (host, integer; sw_processing.py:151-163) ---- */
 /* Number of windows per axis: len(range(0, size - 2*stride, stride)). */
 int32_t ocm_sw_count(int32_t size, int32_t stride);

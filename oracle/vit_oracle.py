@@ -216,3 +216,56 @@ def tile_head_mean_maps(sd, cfg, tiles, patch_size):
         a, _ = compute_attention(attns, 0, crop.shape[-2] // patch_size, crop.shape[-1] // patch_size, patch_size)
         out.append(np.mean(a, axis=0))
     return np.stack(out)
+
+
+def tile_postprocess(rows):
+    """sw_processing.py:245,253-254 on (T, H, P) float32 CLS-row maps: np.mean over heads, per-window
+    (v - min) / (max - min) * 255 — numpy float32 arithmetic, as the reference evaluates it."""
+    rows = np.asarray(rows, dtype=np.float32)
+    out = []
+    for t in range(rows.shape[0]):
+        avg = np.mean(rows[t], axis=0)
+        avg = (avg - avg.min()) / (avg.max() - avg.min())
+        out.append(avg * 255)
+    return np.stack(out)
+
+
+def bilinear_upsample(maps, scale):
+    """cv2.resize(INTER_LINEAR) x scale (sw_processing.py:257) restated with torch's bilinear
+    (align_corners=False = half-pixel centres + border replicate, cv2's geometry for up-scaling).
+    cv2 is an un-vendored dependency that cannot be installed here: PARITY UNPINNED."""
+    t = torch.from_numpy(np.asarray(maps, dtype=np.float32)).unsqueeze(1)
+    return F.interpolate(t, scale_factor=scale, mode="bilinear", align_corners=False)[:, 0].numpy()
+
+
+def otsu_level(img_u8):
+    """cv2.threshold(..., THRESH_OTSU) level: OpenCV 4.6 getThreshVal_Otsu_8u restated (PARITY UNPINNED)."""
+    hist = np.bincount(np.asarray(img_u8, dtype=np.uint8).ravel(), minlength=256).astype(np.float64)
+    scale = 1.0 / hist.sum()
+    mu = float((np.arange(256) * hist).sum() * scale)
+    mu1 = q1 = max_sigma = 0.0
+    level = 0
+    eps = float(np.finfo(np.float32).eps)
+    for i in range(256):
+        p_i = hist[i] * scale
+        mu1 *= q1
+        q1 += p_i
+        q2 = 1.0 - q1
+        if min(q1, q2) < eps or max(q1, q2) > 1.0 - eps:
+            continue
+        mu1 = (mu1 + i * p_i) / q1
+        mu2 = (mu - q1 * mu1) / q2
+        sigma = q1 * q2 * (mu1 - mu2) ** 2
+        if sigma > max_sigma:
+            max_sigma, level = sigma, i
+    return level
+
+
+def heatmap_mask(heat):
+    """threshold() heat-map branch, sw_processing.py:30-35,43,47-48,62."""
+    heat = np.asarray(heat, dtype=np.float32)
+    mn, mx = heat.min(), heat.max()
+    a = heat if mx == mn else (heat - mn) / (mx - mn)
+    img = (a * 255).astype(np.uint8)
+    level = otsu_level(img)
+    return img, np.where(img > level, 255, 0).astype(np.uint8), level

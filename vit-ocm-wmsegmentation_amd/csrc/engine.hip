@@ -516,6 +516,78 @@ extern "C" int ocm_op_attention_map(const float *attn, float *maps, int32_t b, i
 }
 
 // ------------------------------------------------------------------------------------------
+// sliding-window post-processing
+// ------------------------------------------------------------------------------------------
+extern "C" int ocm_op_tile_postprocess(const float *rows, float *maps, int32_t tiles, int32_t heads, int32_t n_rows,
+                                       int32_t pixels, void *stream) {
+    if (!rows || !maps) return fail(OCM_EINVAL, "null argument");
+    if (tiles <= 0 || heads <= 0 || n_rows <= 0 || pixels <= 0) return fail(OCM_EINVAL, "bad shape");
+    HIP_TRY(launch_tile_postprocess(rows, maps, tiles, heads, n_rows, pixels, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_bilinear_upsample(const float *src, float *dst, int32_t tiles, int32_t h, int32_t w,
+                                        int32_t scale, void *stream) {
+    if (!src || !dst) return fail(OCM_EINVAL, "null argument");
+    if (tiles <= 0 || h <= 0 || w <= 0 || scale <= 0) return fail(OCM_EINVAL, "bad shape");
+    HIP_TRY(launch_bilinear_up(src, dst, tiles, h, w, scale, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_stitch(const float *crops, float *out, const double *ramp, int32_t n, int32_t window,
+                             int32_t stride, void *stream) {
+    if (!crops || !out || !ramp) return fail(OCM_EINVAL, "null argument");
+    if (n <= 0 || stride <= 0 || window <= stride || window > 3 * stride)
+        return fail(OCM_EINVAL, "stitch needs stride < window <= 3*stride (got window %d stride %d)", window, stride);
+    HIP_TRY(launch_stitch(crops, out, ramp, n, window, stride, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_normalize_u8(const float *img, int64_t count, void *scratch, uint8_t *out, uint64_t *hist256,
+                                   void *stream) {
+    if (!img || !scratch || !out || !hist256) return fail(OCM_EINVAL, "null argument");
+    if (count <= 0) return fail(OCM_EINVAL, "bad count");
+    HIP_TRY(launch_normalize_u8(img, (size_t)count, (float *)scratch, out, (unsigned long long *)hist256,
+                                (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_threshold_u8(const uint8_t *img, uint8_t *mask, int64_t count, int32_t thresh, void *stream) {
+    if (!img || !mask) return fail(OCM_EINVAL, "null argument");
+    HIP_TRY(launch_threshold_u8(img, mask, (size_t)count, thresh, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+// Otsu threshold of a 256-bin histogram (host). Restates cv2.threshold(..., THRESH_OTSU)'s
+// getThreshVal_Otsu_8u (OpenCV 4.6.0 modules/imgproc/src/thresh.cpp — an un-vendored dependency of the
+// reference, opencv-python 4.6.0.66; parity unpinned: cv2 is not installable here).
+extern "C" int32_t ocm_otsu_threshold(const uint64_t *hist256, int64_t count) {
+    if (!hist256 || count <= 0) return -OCM_EINVAL;
+    const double scale = 1.0 / (double)count;
+    double mu = 0;
+    for (int i = 0; i < 256; ++i) mu += i * (double)hist256[i];
+    mu *= scale;
+    double mu1 = 0, q1 = 0, max_sigma = 0;
+    int max_val = 0;
+    for (int i = 0; i < 256; ++i) {
+        const double p_i = (double)hist256[i] * scale;
+        mu1 *= q1;
+        q1 += p_i;
+        const double q2 = 1.0 - q1;
+        const double lo = q1 < q2 ? q1 : q2, hi = q1 < q2 ? q2 : q1;
+        if (lo < 1.1920928955078125e-07 || hi > 1.0 - 1.1920928955078125e-07) continue;
+        mu1 = (mu1 + i * p_i) / q1;
+        const double mu2 = (mu - q1 * mu1) / q2;
+        const double sigma = q1 * q2 * (mu1 - mu2) * (mu1 - mu2);
+        if (sigma > max_sigma) {
+            max_sigma = sigma;
+            max_val = i;
+        }
+    }
+    return max_val;
+}
+
+// ------------------------------------------------------------------------------------------
 // sliding-window index math (integers, host) — sw_processing.py:151-163 and SURVEY §8-e
 // ------------------------------------------------------------------------------------------
 extern "C" int32_t ocm_sw_count(int32_t size, int32_t stride) {

@@ -39,4 +39,14 @@ hipError_t launch_attention_rows(int prec, const void *q, const void *k, const i
 hipError_t launch_attention_map(const float *attn, float *maps, int b, int heads, int n_tokens, int query, int hf,
                                 int wf, int p, hipStream_t s);
 
+// ---- kernels_post.hip (sliding-window post-processing)
+hipError_t launch_tile_postprocess(const float *rows, float *maps, int tiles, int heads, int n_rows, int pixels,
+                                   hipStream_t s);
+hipError_t launch_bilinear_up(const float *src, float *dst, int tiles, int h, int w, int scale, hipStream_t s);
+hipError_t launch_stitch(const float *crops, float *out, const double *ramp, int n, int window, int stride,
+                         hipStream_t s);
+hipError_t launch_normalize_u8(const float *img, size_t count, float *part, uint8_t *out,
+                               unsigned long long *hist256, hipStream_t s);
+hipError_t launch_threshold_u8(const uint8_t *img, uint8_t *mask, size_t count, int thresh, hipStream_t s);
+
 static inline int ocm_round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -56,6 +56,76 @@ def gather_tile_maps(local, n_tiles, group=None):
     return out[:n_tiles]  # rank r's block starts at r*share; only the tail of the last blocks is padding
 
 
+def _dev_call(t):
+    return torch.cuda.device(t.device)
+
+
+def postprocess_windows(rows, hf, wf, scale):
+    """rows: (T, heads, n_rows, hf*wf) CLS-row maps on a HIP device. Per window, as the tile loop of
+    sw_processing.py:245,253-257 does on the CPU: head mean -> (v - min) / (max - min) * 255 ->
+    (cv2.resize down by 8 of the nearest-upsampled map = the hf x wf map itself) -> cv2.resize
+    INTER_LINEAR up by `scale`. Returns (T, hf*scale, wf*scale) fp32."""
+    _require = rows.is_cuda and rows.dtype == torch.float32
+    if not _require:
+        raise RuntimeError("postprocess_windows needs a float32 tensor on a HIP device (no CPU fallback)")
+    rows = rows.contiguous()
+    T, H, nr, P = rows.shape
+    if P != hf * wf:
+        raise ValueError(f"rows have {P} pixels, expected {hf}x{wf}")
+    lib = _lib.load()
+    small = torch.empty((T, hf, wf), dtype=torch.float32, device=rows.device)
+    big = torch.empty((T, hf * scale, wf * scale), dtype=torch.float32, device=rows.device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    with _dev_call(rows):
+        _lib.check(lib.ocm_op_tile_postprocess(C.c_void_p(rows.data_ptr()), C.c_void_p(small.data_ptr()), T, H, nr, P, st))
+        _lib.check(lib.ocm_op_bilinear_upsample(C.c_void_p(small.data_ptr()), C.c_void_p(big.data_ptr()), T, hf, wf,
+                                                scale, st))
+    return big
+
+
+def stitch_windows(crops, stride, window):
+    """concat_crops (sw_processing.py:113-149) on device: crops (n*n, window, window) fp32 in row-major
+    window order -> (S, S), S = window + (n-1)*stride. Bit-exact with the reference's sequential stitcher."""
+    if not (crops.is_cuda and crops.dtype == torch.float32):
+        raise RuntimeError("stitch_windows needs a float32 tensor on a HIP device (no CPU fallback)")
+    crops = crops.contiguous()
+    n = int(round(crops.shape[0] ** 0.5))
+    if n * n != crops.shape[0] or crops.shape[1] != window or crops.shape[2] != window:
+        raise ValueError(f"expected (n*n, {window}, {window}) crops, got {tuple(crops.shape)}")
+    S = window + (n - 1) * stride
+    ramp = torch.from_numpy(np.linspace(1, 0, window - stride)).to(crops.device)  # float64, as the reference builds it
+    out = torch.empty((S, S), dtype=torch.float32, device=crops.device)
+    with _dev_call(crops):
+        _lib.check(_lib.load().ocm_op_stitch(C.c_void_p(crops.data_ptr()), C.c_void_p(out.data_ptr()),
+                                             C.c_void_p(ramp.data_ptr()), n, window, stride,
+                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
+
+
+def otsu_heatmap_mask(heat):
+    """The heat-map branch of threshold() (sw_processing.py:43-48,62): min_max_normalize -> *255 -> uint8 ->
+    cv2.threshold(THRESH_BINARY + THRESH_OTSU). Returns (uint8 image, uint8 mask in {0,255}, level)."""
+    if not (heat.is_cuda and heat.dtype == torch.float32):
+        raise RuntimeError("otsu_heatmap_mask needs a float32 tensor on a HIP device (no CPU fallback)")
+    heat = heat.contiguous()
+    lib = _lib.load()
+    dev, n = heat.device, heat.numel()
+    img = torch.empty(heat.shape, dtype=torch.uint8, device=dev)
+    mask = torch.empty(heat.shape, dtype=torch.uint8, device=dev)
+    scratch = torch.empty(2048, dtype=torch.uint8, device=dev)
+    hist = torch.empty(256, dtype=torch.int64, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    with _dev_call(heat):
+        _lib.check(lib.ocm_op_normalize_u8(C.c_void_p(heat.data_ptr()), n, C.c_void_p(scratch.data_ptr()),
+                                           C.c_void_p(img.data_ptr()), C.c_void_p(hist.data_ptr()), st))
+        h = hist.cpu().numpy().astype(np.uint64)  # 2 KiB D2H: the level is a 256-step scalar loop
+        level = int(lib.ocm_otsu_threshold(h.ctypes.data_as(C.POINTER(C.c_uint64)), n))
+        if level < 0:
+            raise ValueError("ocm_otsu_threshold failed")
+        _lib.check(lib.ocm_op_threshold_u8(C.c_void_p(img.data_ptr()), C.c_void_p(mask.data_ptr()), n, level, st))
+    return img, mask, level
+
+
 class SlidingWindowAttention:
     """CLS-row attention maps of every window of a slab.
 
@@ -98,3 +168,18 @@ class SlidingWindowAttention:
             local[s:s + nb] = out["rows"]
         maps = gather_tile_maps(local, T, self.group)
         return maps.reshape(T, Hh, nq, hf, wf)
+
+    @torch.no_grad()
+    def segment(self, slab):
+        """The whole of sw_processing.py:223-262 on device: windows -> CLS-row maps (sharded, all-gathered)
+        -> per-window head mean / min-max / x p bilinear upsample -> overlap-blended stitch -> Otsu mask of
+        the heat map. Returns dict(maps, heat (S,S) fp32, image (S,S) uint8, mask (S,S) uint8, level)."""
+        maps = self(slab)
+        T, Hh, _, hf, wf = maps.shape
+        n = int(round(T ** 0.5))
+        if n * n != T:
+            raise ValueError("segment() stitches square window grids (as concat_crops does)")
+        up = postprocess_windows(maps.reshape(T, Hh, 1, hf * wf), hf, wf, self.window // hf)
+        heat = stitch_windows(up, self.stride, self.window)
+        image, mask, level = otsu_heatmap_mask(heat)
+        return dict(maps=maps, heat=heat, image=image, mask=mask, level=level)
