@@ -122,19 +122,19 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
                     S[sub] = mfma32(a, qf[s], S[sub]);
                 }
             }
-            float mx = -INFINITY;
-            const bool tail = (kt + 1) * 64 > N;
+            if ((kt + 1) * 64 > N) {  // tail tile: padding keys -> -inf (wave-uniform branch)
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+                for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = S[sub][e] * scale2;
-                    if (tail && kt * 64 + sub * 32 + key_of_reg(e, h) >= N) v = -INFINITY;
-                    S[sub][e] = v;
-                    mx = fmaxf(mx, v);
-                }
+                    for (int e = 0; e < 16; ++e)
+                        if (kt * 64 + sub * 32 + key_of_reg(e, h) >= N) S[sub][e] = -INFINITY;
+            }
+            // max on the raw scores (scale > 0 commutes with max), scale folded into the exp2 argument
+            float mx = fmaxf(S[0][0], S[1][0]);
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(S[0][e], S[1][e]));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m, mx);  // finite: every tile holds at least one valid key
+            const float mn = fmaxf(m, mx * scale2);  // finite: every tile holds at least one valid key
             const float alpha = fast_exp2(m - mn);
             m = mn;
             float ps = 0.f;
@@ -142,16 +142,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float p = fast_exp2(S[sub][e] - mn);
+                    const float p = fast_exp2(fmaf(S[sub][e], scale2, -mn));
                     S[sub][e] = p;
                     ps += p;
                 }
-            l = l * alpha + ps;
+            l = fmaf(l, alpha, ps);
             if (WANT_O) {
+                if (__any(alpha != 1.0f)) {  // the running max moved somewhere in this wave
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    O[0][e] *= alpha;
-                    O[1][e] *= alpha;
+                    for (int e = 0; e < 16; ++e) {
+                        O[0][e] *= alpha;
+                        O[1][e] *= alpha;
+                    }
                 }
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
