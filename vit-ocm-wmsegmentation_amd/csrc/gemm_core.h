@@ -30,8 +30,19 @@ struct GemmCfg {
     static constexpr int TM = WM / 32, TN = WN / 32;
     static constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;  // 16-B chunks / thread / K-step
     static constexpr int LDS_BYTES = 2 * (BM + BN) * 128;
+    // A wave's 32x32 tiles are INTERLEAVED with the other waves': tile (i, j) of wave (wm, wn) sits at
+    // rows (i*WAVES_M + wm)*32, columns (j*WAVES_N + wn)*32 of the block tile, so the i-th (j-th) tiles
+    // of all waves together cover a contiguous band of RB (CB) rows (columns) — the unit the epilogue
+    // stages through LDS when the whole fp32 tile does not fit.
+    static constexpr int RB = 32 * WAVES_M, CB = 32 * WAVES_N;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging must divide evenly");
+};
+
+// what an epilogue sees of one staged pass: a PBM x PBN fp32 image handled by NT threads
+template <int PBM, int PBN, int NT_>
+struct PassCfg {
+    static constexpr int BM = PBM, BN = PBN, NT = NT_;
 };
 
 // operand element traits: a 16-byte chunk holds EPC elements, an LDS row (one K step) KROW elements
@@ -66,15 +77,15 @@ __device__ __forceinline__ void mma_step(const char *Ab, const char *Bb, int r, 
                                          f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
     if constexpr (sizeof(E) == 2) {
-        // rows wm*WM + 32i + r: the swizzle term (row>>1)&7 only depends on r because the wave / tile row
+        // rows (i*WAVES_M + wm)*32 + r: the swizzle term (row>>1)&7 only depends on r because the tile row
         // offsets are multiples of 32. Lane (r, h) holds k = 16s + 8h .. +7 of row r.
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8 *)(Ab + i * 32 * 128 + lds_off(r, 2 * s + h));
+            for (int i = 0; i < TM; ++i) a[i] = *(const bf16x8 *)(Ab + i * Cfg::RB * 128 + lds_off(r, 2 * s + h));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8 *)(Bb + j * 32 * 128 + lds_off(r, 2 * s + h));
+            for (int j = 0; j < TN; ++j) b[j] = *(const bf16x8 *)(Bb + j * Cfg::CB * 128 + lds_off(r, 2 * s + h));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -90,9 +101,9 @@ __device__ __forceinline__ void mma_step(const char *Ab, const char *Bb, int r, 
         for (int c = 0; c < 4; ++c) {
             f32x4 a[TM], b[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = *(const f32x4 *)(Ab + i * 32 * 128 + lds_off(r, c + 4 * h));
+            for (int i = 0; i < TM; ++i) a[i] = *(const f32x4 *)(Ab + i * Cfg::RB * 128 + lds_off(r, c + 4 * h));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[j] = *(const f32x4 *)(Bb + j * 32 * 128 + lds_off(r, c + 4 * h));
+            for (int j = 0; j < TN; ++j) b[j] = *(const f32x4 *)(Bb + j * Cfg::CB * 128 + lds_off(r, c + 4 * h));
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -104,7 +115,7 @@ __device__ __forceinline__ void mma_step(const char *Ab, const char *Bb, int r, 
     }
 }
 
-// Main loop. acc[i][j] is the 32x32 tile at rows wm*WM+32i, cols wn*WN+32j of the block tile; with
+// Main loop. acc[i][j] is the 32x32 tile at rows (i*WAVES_M+wm)*32, cols (j*WAVES_N+wn)*32 of the block tile; with
 // SWAP the register/lane roles of that tile are transposed (lane = row m). KSTEPS = K / KROW when K
 // is known at compile time (0 = runtime K).
 template <class Cfg, class E, bool SWAP, int KSTEPS, class ALoad>
@@ -155,15 +166,14 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
         for (int i = 0; i < B_CH; ++i) *(Chunk *)(Bs + buf * BN * 128 + b_off[i]) = sl.b[i];
     };
     auto compute = [&](int buf) {
-        mma_step<Cfg, E, SWAP>(As + buf * BM * 128 + (wm * Cfg::WM) * 128, Bs + buf * BN * 128 + (wn * Cfg::WN) * 128, r,
-                               h, acc);
+        mma_step<Cfg, E, SWAP>(As + buf * BM * 128 + (wm * 32) * 128, Bs + buf * BN * 128 + (wn * 32) * 128, r, h, acc);
     };
 
     // Accumulators start at the bias (one load per column / register row, issued together with the
     // first operand tile): the epilogues then add nothing and issue no dependent global loads.
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + wn * Cfg::WN + 32 * j;
+        const int nb = n0 + (j * Cfg::WAVES_N + wn) * 32;
         if (!SWAP) {
             const float bv = bias ? bias[min(nb + r, N - 1)] : 0.f;  // lane = output column
 #pragma unroll
@@ -219,30 +229,68 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
     }
 }
 
-// Epilogue staging: after the main loop's last barrier the operand LDS is free, so every wave
-// drops its fp32 accumulator tiles into a row-major [ROWS][COLS] LDS image (ROWS x COLS = BM x BN,
-// or BN x BM when the accumulator is transposed). The epilogues then read whole 16-B / 32-B row
-// chunks back and issue full-width, fully coalesced global loads/stores with the index math done
-// once per chunk instead of once per element.
-template <class Cfg, bool SWAP>
-__device__ __forceinline__ void stage_acc(const f32x16 (&acc)[Cfg::TM][Cfg::TN], char *smem) {
-    static_assert(Cfg::BM * Cfg::BN * 4 <= Cfg::LDS_BYTES, "C tile must fit the operand LDS");
-    constexpr int COLS = SWAP ? Cfg::BM : Cfg::BN;
-    float *C = (float *)smem;
+// Epilogue: after the main loop's last barrier the operand LDS is free, so the waves drop their fp32
+// accumulator tiles into a row-major LDS image and the epilogue functor reads whole 16-B / 32-B row
+// chunks back and issues full-width, fully coalesced global loads/stores with the index math done once
+// per chunk instead of once per element. When BM x BN fp32 fits the operand LDS this is one pass over
+// the whole tile; bigger tiles go band by band (RB rows of the tile per pass, or CB feature columns when
+// the accumulator is transposed), double-buffered so one LDS-only barrier per pass is enough.
+template <class Cfg, bool SWAP, class Epi>
+__device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::TN], char *smem, const Epi &epi, int m0,
+                                             int n0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
     const int r = lane & 31, h = lane >> 5;
+    if constexpr (Cfg::BM * Cfg::BN * 4 <= Cfg::LDS_BYTES) {
+        constexpr int COLS = SWAP ? Cfg::BM : Cfg::BN;
+        float *C = (float *)smem;
 #pragma unroll
-    for (int i = 0; i < Cfg::TM; ++i)
+        for (int i = 0; i < Cfg::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) {
+                const int tm = (i * Cfg::WAVES_M + wm) * 32, tn = (j * Cfg::WAVES_N + wn) * 32;
+                // normal: lane -> column n, registers -> rows m.  swapped: lane -> m, registers -> n.
+                const int row0 = SWAP ? tn : tm, col = (SWAP ? tm : tn) + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) C[(row0 + acc_row32(e, h)) * COLS + col] = acc[i][j][e];
+            }
+        lds_barrier();
+        epi.template run<PassCfg<Cfg::BM, Cfg::BN, Cfg::NT>>((const float *)C, m0, n0);
+    } else if constexpr (!SWAP) {
+        constexpr int PASS = Cfg::RB * Cfg::BN * 4;  // one band of RB rows
+        static_assert(PASS <= Cfg::LDS_BYTES, "a row band must fit the operand LDS");
+        constexpr int NBUF = 2 * PASS <= Cfg::LDS_BYTES ? 2 : 1;
+#pragma unroll
+        for (int i = 0; i < Cfg::TM; ++i) {
+            if (NBUF == 1 && i) lds_barrier();  // the band's readers are done
+            float *C = (float *)(smem + (i % NBUF) * PASS);
+#pragma unroll
+            for (int j = 0; j < Cfg::TN; ++j) {
+                const int col = (j * Cfg::WAVES_N + wn) * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) C[(wm * 32 + acc_row32(e, h)) * Cfg::BN + col] = acc[i][j][e];
+            }
+            lds_barrier();  // also orders pass i-2's reads of this buffer before pass i's writes (see above)
+            epi.template run<PassCfg<Cfg::RB, Cfg::BN, Cfg::NT>>((const float *)C, m0 + i * Cfg::RB, n0);
+        }
+    } else {
+        constexpr int PASS = Cfg::CB * Cfg::BM * 4;  // one band of CB feature rows of the transposed tile
+        static_assert(PASS <= Cfg::LDS_BYTES, "a column band must fit the operand LDS");
+        constexpr int NBUF = 2 * PASS <= Cfg::LDS_BYTES ? 2 : 1;
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) {
-            const int tm = wm * Cfg::WM + 32 * i, tn = wn * Cfg::WN + 32 * j;
-            // normal: lane -> column n, registers -> rows m.  swapped: lane -> m, registers -> n.
-            const int row0 = SWAP ? tn : tm, col = (SWAP ? tm : tn) + r;
+            if (NBUF == 1 && j) lds_barrier();
+            float *C = (float *)(smem + (j % NBUF) * PASS);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) C[(row0 + acc_row32(e, h)) * COLS + col] = acc[i][j][e];
+            for (int i = 0; i < Cfg::TM; ++i) {
+                const int col = (i * Cfg::WAVES_M + wm) * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) C[(wn * 32 + acc_row32(e, h)) * Cfg::BM + col] = acc[i][j][e];
+            }
+            lds_barrier();
+            epi.template run<PassCfg<Cfg::BM, Cfg::CB, Cfg::NT>>((const float *)C, m0, n0 + j * Cfg::CB);
         }
-    lds_barrier();
+    }
 }
 
 // Generic kernel: grid = tiles_m * tiles_n workgroups (linear, XCD-remapped so the
@@ -257,6 +305,5 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const E *__rest
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
     gemm_mainloop<Cfg, E, SWAP, KSTEPS>(al, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
-    stage_acc<Cfg, SWAP>(acc, smem);
-    epi.template run<Cfg>((const float *)smem, m0, n0);
+    run_epilogue<Cfg, SWAP>(acc, smem, epi, m0, n0);
 }

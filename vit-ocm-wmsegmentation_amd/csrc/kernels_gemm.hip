@@ -11,6 +11,15 @@
 typedef GemmCfg<128, 128, 2, 2> Cfg128x128;
 typedef GemmCfg<64, 128, 2, 2> Cfg64x128;
 typedef GemmCfg<64, 64, 2, 2> Cfg64x64;
+// 8 waves, one workgroup per CU: half the L2->LDS bytes per output element of 128x128. Pays off once the
+// problem has at least two full rounds of such tiles (ViT-B at 384^2, the ViT-S/8 slab windows); below
+// that the idle CUs of the last round cost more than the traffic saves, and with K = 384 (six steps) the
+// exposed prologue of a lone workgroup does (measured: ViT-S/8 slab fc1 +7 % slower, ViT-B GEMMs 13 % faster).
+typedef GemmCfg<256, 256, 2, 4> Cfg256x256;
+
+static inline bool big_tiles_pay(int M, int N, int K) {
+    return K >= 768 && N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) >= 512;
+}
 
 // 16-byte store of 16/sizeof(OE) consecutive outputs taken from fp32 values
 __device__ __forceinline__ void store_chunk(bf16 *dst, const f32x4 &v0, const f32x4 &v1) { *(bf16x8 *)dst = cvt8(v0, v1); }
@@ -37,23 +46,20 @@ struct EpiLinear {
         constexpr bool ACT_OUT = (MODE == 2 || MODE == 3);
         constexpr int W = ACT_OUT ? 16 / (int)sizeof(OE) : 4;  // columns per lane
         constexpr int CPR = BN / W;                            // chunks per row
-        constexpr int ITERS = BM * CPR / NT;
-        static_assert(NT % CPR == 0, "a lane keeps one column chunk");
-        const int col = (threadIdx.x % CPR) * W, row0 = threadIdx.x / CPR;
-        const int n = n0 + col;
-        if (n >= N) return;
+        constexpr int TOTAL = BM * CPR, ITERS = (TOTAL + NT - 1) / NT;
         f32x4 rs[MODE == 1 ? ITERS : 1];
         if (MODE == 1) {
 #pragma unroll
             for (int i = 0; i < ITERS; ++i) {
-                const int m = min(m0 + row0 + i * (NT / CPR), M - 1);
-                rs[i] = *(const f32x4 *)(resid + (int64_t)m * ldo + n);
+                const int q = min((int)threadIdx.x + i * NT, TOTAL - 1), row = q / CPR, col = (q - row * CPR) * W;
+                rs[i] = *(const f32x4 *)(resid + (int64_t)min(m0 + row, M - 1) * ldo + min(n0 + col, N - W));
             }
         }
 #pragma unroll
         for (int i = 0; i < ITERS; ++i) {
-            const int row = row0 + i * (NT / CPR), m = m0 + row;
-            if (m >= M) continue;
+            const int q = threadIdx.x + i * NT, row = q / CPR, col = (q - row * CPR) * W;
+            const int m = m0 + row, n = n0 + col;
+            if ((TOTAL % NT != 0 && q >= TOTAL) || m >= M || n >= N) continue;
             const int64_t o = (int64_t)m * ldo + n;
             f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
             if (!ACT_OUT) {
@@ -119,6 +125,8 @@ static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, 
                                      int N, int K, hipStream_t s) {
     RowLoader<E> al{a, K};
     EpiLinear<MODE, E> epi{bias, resid, out, M, N, N};
+    if constexpr (sizeof(E) == 2)
+        if (big_tiles_pay(M, N, K)) return launch_gemm<Cfg256x256, E, false>(al, w, K, M, N, K, epi, s);
     // Tile choice: fill >= 2 workgroups per CU (256 CUs) when the problem allows it.
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (N % 128 == 0 && t128 >= 512) return launch_gemm<Cfg128x128, E, false>(al, w, K, M, N, K, epi, s);
@@ -199,12 +207,15 @@ struct EpiVt {
     template <class Cfg>
     __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
+        constexpr int RS = NT >= BM ? NT / BM : 1;  // feature rows handled per sweep
+        static_assert(NT >= BM, "one lane per token column");
+        if (threadIdx.x >= RS * BM) return;
         const int col = threadIdx.x % BM, m = m0 + col;
         if (m >= M) return;
         const int b = m / ntok, t = m - b * ntok;
         const int rem0 = n0 - 2 * D;
 #pragma unroll 4
-        for (int row = threadIdx.x / BM; row < BN; row += NT / BM) {
+        for (int row = threadIdx.x / BM; row < BN; row += RS) {
             const int rem = rem0 + row, head = rem >> 6, d = rem & 63;
             const float v = C[row * BM + col];
             vt[((int64_t)(b * H + head) * 64 + d) * npad + t] = (E)v;
@@ -225,12 +236,10 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader<E> al, const E *
     f32x16 acc[Cfg::TM][Cfg::TN];
     if (n0 < 2 * D) {  // workgroup-uniform
         gemm_mainloop<Cfg, E, false, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
-        stage_acc<Cfg, false>(acc, smem);
-        eqk.template run<Cfg>((const float *)smem, m0, n0);
+        run_epilogue<Cfg, false>(acc, smem, eqk, m0, n0);
     } else {
         gemm_mainloop<Cfg, E, true, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
-        stage_acc<Cfg, true>(acc, smem);
-        ev.template run<Cfg>((const float *)smem, m0, n0);
+        run_epilogue<Cfg, true>(acc, smem, ev, m0, n0);
     }
 }
 
@@ -269,6 +278,8 @@ static hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, 
     RowLoader<E> al{a, D};
     EpiQK<E> eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
     EpiVt<E> ev{bias, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
+    if constexpr (sizeof(E) == 2)
+        if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_cfg<Cfg256x256, E>(al, w, M, D, eqk, ev, s);
     const long t128 = (long)((M + 127) / 128) * (3 * D / 128);
     if (D % 128 == 0 && t128 >= 512) return launch_qkv_cfg<Cfg128x128, E>(al, w, M, D, eqk, ev, s);
     if (D % 128 == 0) return launch_qkv_cfg<Cfg64x128, E>(al, w, M, D, eqk, ev, s);
