@@ -59,6 +59,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// The same remap for a 2-D grid (x fastest, as the dispatcher walks it): returns the logical (x, y).
+// Every kernel of the layer chain maps token rows / (image, head) pairs to XCDs the same way — contiguous
+// eighths — so a stage reads what the previous stage left in ITS XCD's L2 instead of going to the
+// Infinity Cache for it.
+__device__ __forceinline__ void xcd_remap2(int &bx, int &by) {
+    const int id = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    by = id / (int)gridDim.x;
+    bx = id - by * (int)gridDim.x;
+}
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. fp32-grade) on the hardware
 // reciprocal / exp2 units: ~12 VALU ops instead of libm erff's ~50, which made the fc1 epilogue
 // cost more than its MFMA main loop.

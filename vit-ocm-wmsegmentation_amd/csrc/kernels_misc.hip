@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
                                                         int64_t rows, int dim, float eps) {
     constexpr int MAXV = 8;  // dim <= 1024
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t row = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float *xr = x + row * dim;
     f32x2 v[MAXV];
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float *__restri
                                                            int64_t rows, float eps) {
     constexpr int dim = NV * 128;
     const int sub = threadIdx.x & 31;
-    const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int64_t row = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 8 + (threadIdx.x >> 5);
     if (row >= rows) return;
     const float *xr = x + row * dim;
     f32x4 v[NV];
