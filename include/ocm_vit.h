@@ -253,6 +253,19 @@ int ocm_op_normalize_u8(const float *img, int64_t count, void *scratch, uint8_t 
 int32_t ocm_otsu_threshold(const uint64_t *hist256_host, int64_t count);
 int ocm_op_threshold_u8(const uint8_t *img, uint8_t *mask, int64_t count, int32_t thresh, void *stream);
 
+/* ---- eval.py's per-image mask chain (eval.py:126-171, utils.py:55-115 threshold()) ---- */
+/* eval.py:142 — np.mean(attention_response, axis=0): rows (T,H,n_rows,P) -> maps (T,P), sequential fp32. */
+int ocm_op_head_mean(const float *rows, float *maps, int32_t tiles, int32_t heads, int32_t n_rows,
+                     int32_t pixels, void *stream);
+/* eval.py:122,166 — transform(img).convert("L"): float planes (1 or 3, `stride_c` elements apart) ->
+ * uint8 by mul(255).byte() and PIL's integer RGB->L weights; optional 256-bin histogram. */
+int ocm_op_image_to_gray_u8(const float *image, int64_t stride_c, int32_t chans, int64_t count, uint8_t *out,
+                            uint64_t *hist256, void *stream);
+/* utils.py:76-81 — result = ((img / 2) * (1 - alpha) + (attention / 2) * alpha).astype(uint8) in float64;
+ * `one_minus_alpha` is the host's own (1 - alpha) double. Optional histogram of the result. */
+int ocm_op_blend_u8(const uint8_t *img, const uint8_t *att, int64_t count, double alpha, double one_minus_alpha,
+                    uint8_t *out, uint64_t *hist256, void *stream);
+
 /* ---- sliding-window index math (host, integer; sw_processing.py:151-163) ---- */
 /* Number of windows per axis: len(range(0, size - 2*stride, stride)). */
 int32_t ocm_sw_count(int32_t size, int32_t stride);

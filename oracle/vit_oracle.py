@@ -269,3 +269,44 @@ def heatmap_mask(heat):
     img = (a * 255).astype(np.uint8)
     level = otsu_level(img)
     return img, np.where(img > level, 255, 0).astype(np.uint8), level
+
+
+# ------------------------------------------------------------------------------------------------
+# eval.py's per-image mask chain (eval.py:126-171 with the default --crop 1 --median_filter 1, and
+# utils.py:55-115 threshold()). cv2 / torchvision / PIL arithmetic is restated: PARITY UNPINNED.
+# ------------------------------------------------------------------------------------------------
+def to_pil_gray_u8(img_chw):
+    """transform(img.squeeze(0)).convert("L") (eval.py:122,166): torchvision ToPILImage on a float CHW
+    tensor is pic.mul(255).byte(); PIL's RGB->L is (19595 R + 38470 G + 7471 B + 0x8000) >> 16."""
+    a = (np.asarray(img_chw, dtype=np.float32) * np.float32(255)).astype(np.int32).astype(np.uint8).astype(np.uint32)
+    if a.shape[0] == 1:
+        return a[0].astype(np.uint8)
+    return ((19595 * a[0] + 38470 * a[1] + 7471 * a[2] + 0x8000) >> 16).astype(np.uint8)
+
+
+def eval_average_attention(cls_rows, hf, wf, patch_size):
+    """eval.py:136-144,164-166 for one image: cls_rows (H, hf*wf) = attentions[0][0, :, 0, 1:] ->
+    nearest x p -> np.mean over heads -> median_filter(size=1) (identity) -> cv2.resize down by p (returns
+    the hf x wf block values) -> cv2.resize INTER_LINEAR up to the image size."""
+    rows = np.asarray(cls_rows, dtype=np.float32)
+    s = rows[0].copy()
+    for h in range(1, rows.shape[0]):
+        s = s + rows[h]
+    avg = (s / np.float32(rows.shape[0])).astype(np.float32).reshape(1, hf, wf)
+    return bilinear_upsample(avg, patch_size)[0]
+
+
+def threshold_masks(img_u8, attention):
+    """utils.py:61-115 threshold(img, attention, save=False) -> (th, th2, th3) plus the Otsu levels."""
+    attention = np.asarray(attention, dtype=np.float32)
+    mn, mx = attention.min(), attention.max()
+    att = attention if mx == mn else (attention - mn) / (mx - mn)
+    img = np.asarray(img_u8, dtype=np.uint8)
+    alpha = 0.4
+    att = (att * 255).astype(np.uint8)
+    result = ((img / 2) * (1 - alpha) + (att / 2) * alpha).astype(np.uint8)
+    l1, l2, l3 = otsu_level(result), otsu_level(img), otsu_level(att)
+    th = np.where(result > l1, 255, 0).astype(np.uint8)
+    th2 = (img > l2).astype(np.uint8) * 255
+    th3 = np.where(att > l3, 255, 0).astype(np.uint8)
+    return (th, th2, th3), (l1, l2, l3), result

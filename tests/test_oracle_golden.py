@@ -82,3 +82,18 @@ def test_helpers_match_reference_golden():
         rng = np.random.default_rng(int(gold[f"stitch_{n}_seed"]))
         crops = np.stack([rng.random((384, 384), dtype=np.float32) * 255 for _ in range(n * n)])
         assert np.array_equal(O.concat_crops(crops, 128, 384), gold[f"stitch_{n}"])
+
+
+def test_oracle_threshold_chain_properties():
+    """utils.py:61-115 restatement: PIL grey conversion is the identity on R=G=B planes, a flat attention map
+    leaves min_max_normalize inactive, and Otsu separates a clean bimodal image between its two modes."""
+    rng = np.random.default_rng(0)
+    g = rng.uniform(0, 1, (1, 40, 40)).astype(np.float32)
+    u1 = O.to_pil_gray_u8(g)
+    assert np.array_equal(u1, O.to_pil_gray_u8(np.repeat(g, 3, 0)))
+    assert np.array_equal(u1, (g[0] * np.float32(255)).astype(np.uint8))
+    img = np.where(np.arange(1600).reshape(40, 40) % 3 == 0, 200, 40).astype(np.uint8)
+    (th, th2, th3), (l1, l2, l3), result = O.threshold_masks(img, np.full((40, 40), 0.5, np.float32))
+    assert 40 <= l2 < 200 and np.array_equal(th2, np.where(img > l2, 255, 0))
+    assert np.array_equal(result, ((img / 2) * 0.6 + (127 / 2) * 0.4).astype(np.uint8))  # flat map: 0.5*255 -> 127
+    assert set(np.unique(th3)) <= {0, 255}

@@ -552,6 +552,32 @@ extern "C" int ocm_op_normalize_u8(const float *img, int64_t count, void *scratc
     return OCM_OK;
 }
 
+extern "C" int ocm_op_head_mean(const float *rows, float *maps, int32_t tiles, int32_t heads, int32_t n_rows,
+                                int32_t pixels, void *stream) {
+    if (!rows || !maps) return fail(OCM_EINVAL, "null argument");
+    if (tiles <= 0 || heads <= 0 || n_rows <= 0 || pixels <= 0) return fail(OCM_EINVAL, "bad shape");
+    HIP_TRY(launch_head_mean(rows, maps, tiles, heads, n_rows, pixels, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_image_to_gray_u8(const float *image, int64_t stride_c, int32_t chans, int64_t count, uint8_t *out,
+                                       uint64_t *hist256, void *stream) {
+    if (!image || !out) return fail(OCM_EINVAL, "null argument");
+    if (count <= 0 || (chans != 1 && chans != 3)) return fail(OCM_EINVAL, "image_to_gray_u8 takes 1 or 3 planes");
+    HIP_TRY(launch_image_to_gray_u8(image, stride_c, chans, (size_t)count, out, (unsigned long long *)hist256,
+                                    (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_blend_u8(const uint8_t *img, const uint8_t *att, int64_t count, double alpha,
+                               double one_minus_alpha, uint8_t *out, uint64_t *hist256, void *stream) {
+    if (!img || !att || !out) return fail(OCM_EINVAL, "null argument");
+    if (count <= 0) return fail(OCM_EINVAL, "bad count");
+    HIP_TRY(launch_blend_u8(img, att, (size_t)count, alpha, one_minus_alpha, out, (unsigned long long *)hist256,
+                            (hipStream_t)stream));
+    return OCM_OK;
+}
+
 extern "C" int ocm_op_threshold_u8(const uint8_t *img, uint8_t *mask, int64_t count, int32_t thresh, void *stream) {
     if (!img || !mask) return fail(OCM_EINVAL, "null argument");
     HIP_TRY(launch_threshold_u8(img, mask, (size_t)count, thresh, (hipStream_t)stream));

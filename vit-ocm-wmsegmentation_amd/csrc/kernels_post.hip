@@ -30,6 +30,7 @@ __device__ __forceinline__ float block_reduce(float v, float *scratch, bool is_m
 //   avg = np.mean over heads (sequential fp32 sum, then / H)                       sw_processing.py:245
 //   maps = (avg - avg.min()) / (avg.max() - avg.min()) * 255                       :253-254
 // The reference takes the mean / min / max of the nearest-upsampled (x p) map: same values.
+template <bool NORMALIZE>
 __global__ __launch_bounds__(256) void tile_post_kernel(const float *__restrict__ rows, float *__restrict__ maps,
                                                         int H, int n_rows, int P) {
     __shared__ float scratch[4];
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(256) void tile_post_kernel(const float *__restrict_
         mn = fminf(mn, s);
         mx = fmaxf(mx, s);
     }
+    if (!NORMALIZE) return;  // eval.py:142 keeps the plain head mean
     mn = block_reduce(mn, scratch, false);
     mx = block_reduce(mx, scratch, true);
     const float range = mx - mn;
@@ -55,7 +57,13 @@ __global__ __launch_bounds__(256) void tile_post_kernel(const float *__restrict_
 hipError_t launch_tile_postprocess(const float *rows, float *maps, int tiles, int heads, int n_rows, int pixels,
                                    hipStream_t s) {
     if (tiles <= 0) return hipSuccess;
-    tile_post_kernel<<<dim3(tiles), dim3(256), 0, s>>>(rows, maps, heads, n_rows, pixels);
+    tile_post_kernel<true><<<dim3(tiles), dim3(256), 0, s>>>(rows, maps, heads, n_rows, pixels);
+    return hipGetLastError();
+}
+
+hipError_t launch_head_mean(const float *rows, float *maps, int tiles, int heads, int n_rows, int pixels, hipStream_t s) {
+    if (tiles <= 0) return hipSuccess;
+    tile_post_kernel<false><<<dim3(tiles), dim3(256), 0, s>>>(rows, maps, heads, n_rows, pixels);
     return hipGetLastError();
 }
 
@@ -212,5 +220,70 @@ __global__ __launch_bounds__(256) void threshold_u8_kernel(const uint8_t *__rest
 
 hipError_t launch_threshold_u8(const uint8_t *img, uint8_t *mask, size_t count, int thresh, hipStream_t s) {
     threshold_u8_kernel<<<dim3(1024), dim3(256), 0, s>>>(img, mask, count, thresh);
+    return hipGetLastError();
+}
+
+// ---- eval.py's per-image mask chain (eval.py:126-171 -> utils.py:61-115 threshold()) ----
+// transform(img).convert("L") (eval.py:122,166): torchvision ToPILImage of a float CHW tensor is
+// pic.mul(255).byte() (truncation), PIL's RGB -> L is (19595 R + 38470 G + 7471 B + 0x8000) >> 16.
+__global__ __launch_bounds__(256) void image_to_gray_u8_kernel(const float *__restrict__ img, int64_t stride_c, int chans,
+                                                               size_t count, uint8_t *__restrict__ out,
+                                                               unsigned long long *hist) {
+    __shared__ unsigned int lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        unsigned int u;
+        if (chans == 1) {
+            u = (uint8_t)(int)(img[i] * 255.0f);
+        } else {
+            const unsigned int r = (uint8_t)(int)(img[i] * 255.0f), g = (uint8_t)(int)(img[stride_c + i] * 255.0f),
+                               b = (uint8_t)(int)(img[2 * stride_c + i] * 255.0f);
+            u = (19595u * r + 38470u * g + 7471u * b + 0x8000u) >> 16;
+        }
+        out[i] = (uint8_t)u;
+        if (hist) atomicAdd(&lh[u], 1u);
+    }
+    __syncthreads();
+    if (hist && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+hipError_t launch_image_to_gray_u8(const float *img, int64_t stride_c, int chans, size_t count, uint8_t *out,
+                                   unsigned long long *hist256, hipStream_t s) {
+    if (hist256) {
+        hipError_t e = hipMemsetAsync(hist256, 0, 256 * sizeof(unsigned long long), s);
+        if (e != hipSuccess) return e;
+    }
+    image_to_gray_u8_kernel<<<dim3(1024), dim3(256), 0, s>>>(img, stride_c, chans, count, out, hist256);
+    return hipGetLastError();
+}
+
+// utils.py:79-80: result = (img / 2) * (1 - alpha) + (attention / 2) * alpha in float64 (numpy promotes
+// uint8 / int to double), then astype(np.uint8) (truncation). one_minus_alpha is passed in as the host
+// computed it (Python's 1 - 0.4), so the device multiplies by the very same doubles.
+__global__ __launch_bounds__(256) void blend_u8_kernel(const uint8_t *__restrict__ img, const uint8_t *__restrict__ att,
+                                                       size_t count, double alpha, double one_minus_alpha,
+                                                       uint8_t *__restrict__ out, unsigned long long *hist) {
+    __shared__ unsigned int lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        const double a = ((double)img[i] / 2.0) * one_minus_alpha;
+        const double b = ((double)att[i] / 2.0) * alpha;
+        const uint8_t u = (uint8_t)(int)(a + b);
+        out[i] = u;
+        if (hist) atomicAdd(&lh[u], 1u);
+    }
+    __syncthreads();
+    if (hist && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+hipError_t launch_blend_u8(const uint8_t *img, const uint8_t *att, size_t count, double alpha, double one_minus_alpha,
+                           uint8_t *out, unsigned long long *hist256, hipStream_t s) {
+    if (hist256) {
+        hipError_t e = hipMemsetAsync(hist256, 0, 256 * sizeof(unsigned long long), s);
+        if (e != hipSuccess) return e;
+    }
+    blend_u8_kernel<<<dim3(1024), dim3(256), 0, s>>>(img, att, count, alpha, one_minus_alpha, out, hist256);
     return hipGetLastError();
 }

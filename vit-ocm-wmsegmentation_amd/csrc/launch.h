@@ -48,5 +48,10 @@ hipError_t launch_stitch(const float *crops, float *out, const double *ramp, int
 hipError_t launch_normalize_u8(const float *img, size_t count, float *part, uint8_t *out,
                                unsigned long long *hist256, hipStream_t s);
 hipError_t launch_threshold_u8(const uint8_t *img, uint8_t *mask, size_t count, int thresh, hipStream_t s);
+hipError_t launch_head_mean(const float *rows, float *maps, int tiles, int heads, int n_rows, int pixels, hipStream_t s);
+hipError_t launch_image_to_gray_u8(const float *img, int64_t stride_c, int chans, size_t count, uint8_t *out,
+                                   unsigned long long *hist256, hipStream_t s);
+hipError_t launch_blend_u8(const uint8_t *img, const uint8_t *att, size_t count, double alpha, double one_minus_alpha,
+                           uint8_t *out, unsigned long long *hist256, hipStream_t s);
 
 static inline int ocm_round_up(int v, int m) { return (v + m - 1) / m * m; }
