@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCM_ABI_VERSION 2
+#define OCM_ABI_VERSION 3
 
 enum {
     OCM_OK = 0,
@@ -79,6 +79,7 @@ void ocm_vit_destroy(ocm_vit_t *h);
  *   blocks.{i}.attn.qkv.{weight,bias}, blocks.{i}.attn.proj.{weight,bias},
  *   blocks.{i}.norm2.{weight,bias}, blocks.{i}.mlp.fc1.{weight,bias},
  *   blocks.{i}.mlp.fc2.{weight,bias}, norm.{weight,bias}
+ * and, optionally, mask_token (model.py:16; only needed when ocm_vit_io.patch_mask is used)
  * (`pos_embed` is passed per forward, see ocm_vit_io.pos_embed).
  * `dev_src` is a contiguous fp32 device buffer of `count` elements in the
  * reference's layout; the engine keeps its own packed (bf16 for matrices, fp32
@@ -97,8 +98,10 @@ enum {
     OCM_OUT_TOKENS = 1 << 3,    /* raw residual stream after the last block (no final norm)         */
     OCM_OUT_ROWS = 1 << 4,      /* selected query rows of the last block's attention, CLS column
                                    dropped: (B,H,n_rows,N-1)          (utils.py:229-233)            */
-    OCM_LAST_ATTN_ONLY = 1 << 5 /* get_last_selfattention (:239-246): the last block stops after
+    OCM_LAST_ATTN_ONLY = 1 << 5,/* get_last_selfattention (:239-246): the last block stops after
                                    its attention probabilities; FEAT/TOKENS/QKV must not be set.    */
+    OCM_OUT_FMAP = 1 << 6       /* norm(x)[:, 1:] as a (B,D,hp,wp) feature map — what the encoders of
+                                   model.py:48-53,134-139 return                                   */
 };
 
 /* One batch of tiles through prepare_tokens + blocks [+ final norm].
@@ -129,6 +132,10 @@ typedef struct ocm_vit_io {
     int32_t n_rows;
     int32_t reserved;
     float *out_rows;             /* dev, [B][H][n_rows][N-1]          or NULL       */
+    const float *patch_mask;     /* dev, [B][P] fp32 SimMIM mask w or NULL: patch rows become
+                                    x*(1-w) + mask_token*w before cls/pos (model.py:28-33); needs the
+                                    optional parameter "mask_token"                 */
+    float *out_fmap;             /* dev, [B][D][hp][wp]               or NULL       */
     void *workspace;             /* dev, >= ocm_vit_workspace_bytes(h, batch, N)    */
     size_t workspace_bytes;
     void *stream;                /* hipStream_t                                     */
@@ -265,6 +272,12 @@ int ocm_op_image_to_gray_u8(const float *image, int64_t stride_c, int32_t chans,
  * `one_minus_alpha` is the host's own (1 - alpha) double. Optional histogram of the result. */
 int ocm_op_blend_u8(const uint8_t *img, const uint8_t *att, int64_t count, double alpha, double one_minus_alpha,
                     uint8_t *out, uint64_t *hist256, void *stream);
+
+/* ---- decoder head of model.py:60-66,147-152: Conv2d(D, s*s*C_out, 1) + PixelShuffle(s) ---- */
+/* lin: (B*hp*wp, s*s*c_out) fp32 = the 1x1 conv evaluated token-major (ocm_op_linear on the normed patch
+ * tokens); out: (B, c_out, hp*s, wp*s) with out[b][c][y*s+i][x*s+j] = lin[b*hp*wp + y*wp + x][c*s*s + i*s + j]. */
+int ocm_op_pixel_shuffle(const float *lin, float *out, int32_t batch, int32_t hp, int32_t wp, int32_t c_out,
+                         int32_t s, void *stream);
 
 /* ---- sliding-window index math (host, integer; sw_processing.py:151-163) ---- */
 /* Number of windows per axis: len(range(0, size - 2*stride, stride)). */

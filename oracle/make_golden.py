@@ -34,7 +34,7 @@ from vit_ocm_wmsegmentation_amd import synth  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 TOL = 1e-6
 
-from tests.golden_cases import CASES  # noqa: E402  (shared with the tests)
+from tests.golden_cases import CASES, WRAPPER_CASES  # noqa: E402  (shared with the tests)
 
 
 def build_reference(case):
@@ -161,10 +161,80 @@ def run_helpers():
           f"({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def run_wrappers():
+    """Pin the model.py wrappers with the reference's OWN classes. model.py imports timm
+    (absent here) for one initialiser, so the class definitions are compiled from its AST with the reference's
+    VisionTransformer and the reference's own dino.utils.trunc_normal_ in scope (every parameter is then
+    overwritten by the synthetic state_dict)."""
+    import torch.nn.functional as F
+    from dino.utils import trunc_normal_ as ref_trunc_normal_
+
+    from oracle.ref_extract import load_classes
+    ns = {"torch": torch, "nn": nn, "F": F, "partial": partial, "VisionTransformer": ref_vits.VisionTransformer,
+          "trunc_normal_": ref_trunc_normal_, "vits": ref_vits, "os": os}
+    ref = load_classes(os.path.join(REF, "model.py"),
+                       ["VisionTransformerForSimMIM", "MIM", "VisionTransformerForFinetune", "LinearProbing"], ns)
+    out = {}
+    worst = 0.0
+    for name, c in WRAPPER_CASES.items():
+        D, L, H, p, S, B = c["dim"], c["depth"], c["heads"], c["patch"], c["img_size"], c["batch"]
+        kw = dict(patch_size=p, embed_dim=D, depth=L, num_heads=H, mlp_ratio=4, img_size=[S], qkv_bias=True,
+                  norm_layer=partial(nn.LayerNorm, eps=1e-6), interpolate_encoding=True)
+        sd = synth.synth_state_dict(D, L, p, seed=c["seed"], variant=c["variant"], img_size=224)
+        cfg = O.make_cfg(sd, p, H)
+        x = synth.synth_tiles(B, S, seed=c["seed"] + 100)
+        mask = synth.synth_patch_mask(B, S // p, seed=c["seed"])
+        # --- VisionTransformerForFinetune + LinearProbing (one-layer decoder)
+        wp1 = synth.synth_wrapper_params(D, p, 1, seed=c["seed"])
+        enc = ref["VisionTransformerForFinetune"](**kw)
+        assert not enc.load_state_dict(sd, strict=True).missing_keys
+        lp = ref["LinearProbing"](enc, p).eval()
+        lp.one_layer_decoder[0].weight.data.copy_(wp1["decoder.weight"])
+        lp.one_layer_decoder[0].bias.data.copy_(wp1["decoder.bias"])
+        with torch.no_grad():
+            z = enc(x)
+            rec1 = lp(x)
+        oz = O.encoder_fmap(sd, cfg, x, S)
+        orec1 = O.conv1x1_pixel_shuffle(oz, wp1["decoder.weight"], wp1["decoder.bias"], p)
+        d = [maxdiff(z, oz), maxdiff(rec1, orec1)]
+        # --- VisionTransformerForSimMIM + MIM
+        wp3 = synth.synth_wrapper_params(D, p, 3, seed=c["seed"])
+        enc_m = ref["VisionTransformerForSimMIM"](**kw)
+        sdm = dict(sd, mask_token=wp3["mask_token"])
+        assert not enc_m.load_state_dict(sdm, strict=True).missing_keys
+        mim = ref["MIM"](enc_m, p).eval()
+        mim.patch_size = p  # the reference hard-codes 8 (model.py:67); keep the mask upsample consistent with p
+        mim.decoder[0].weight.data.copy_(wp3["decoder.weight"])
+        mim.decoder[0].bias.data.copy_(wp3["decoder.bias"])
+        with torch.no_grad():
+            zm = enc_m(x, mask)
+            loss, rec3, mup = mim(x, mask)
+        ozm = O.encoder_fmap(sd, cfg, x, S, mask=mask, mask_token=wp3["mask_token"])
+        oloss, orec3, omup = O.mim_forward(sd, cfg, x, mask, S, wp3["mask_token"], wp3["decoder.weight"],
+                                           wp3["decoder.bias"], p, patch_size=p)
+        d += [maxdiff(zm, ozm), maxdiff(rec3, orec3), abs(float(loss) - float(oloss))]
+        assert torch.equal(mup, omup)
+        assert max(d) <= TOL, f"{name}: oracle vs reference {max(d):.3e}"
+        worst = max(worst, max(d))
+        out[name + "_fmap"] = z.numpy()
+        out[name + "_rec1"] = rec1.numpy()
+        out[name + "_fmap_masked"] = zm.numpy()
+        out[name + "_rec3"] = rec3.numpy()
+        out[name + "_loss"] = np.float64(float(loss))
+    out["oracle_vs_reference_maxabs"] = np.float64(worst)
+    path = os.path.join(GOLD, "wrappers.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrappers           model.py encoders / decoders pinned, max|d| = {worst:.2e} -> {os.path.relpath(path, ROOT)} "
+          f"({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if "--only-wrappers" in sys.argv:
+        return run_wrappers()
     run_helpers()
+    run_wrappers()
     for name, case in CASES.items():
         run_case(name, case)
 

@@ -19,3 +19,16 @@ def load_functions(path, names):
     ns = {"np": np, "torch": torch, "nn": nn}
     exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
     return {n: ns[n] for n in names}
+
+
+def load_classes(path, names, namespace):
+    """Same for CLASS definitions (model.py imports timm, absent here; the classes on the path only need torch
+    and the reference's own VisionTransformer / trunc_normal_, which the caller supplies in `namespace`)."""
+    tree = ast.parse(open(path).read(), filename=path)
+    picked = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name in names]
+    missing = set(names) - {n.name for n in picked}
+    if missing:
+        raise KeyError(f"{path}: classes {sorted(missing)} not found")
+    ns = dict(namespace)
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return {n: ns[n] for n in names}

@@ -310,3 +310,44 @@ def threshold_masks(img_u8, attention):
     th2 = (img > l2).astype(np.uint8) * 255
     th3 = np.where(att > l3, 255, 0).astype(np.uint8)
     return (th, th2, th3), (l1, l2, l3), result
+
+
+# ------------------------------------------------------------------------------------------------
+# model.py wrappers. Pinned against the reference's own classes, extracted from
+# model.py by oracle/ref_extract.py (the module itself imports timm, absent here): oracle/make_golden.py.
+# ------------------------------------------------------------------------------------------------
+def encoder_fmap(sd, cfg, x, img_size, mask=None, mask_token=None):
+    """VisionTransformerForSimMIM.forward (model.py:24-53) when `mask` is given, else
+    VisionTransformerForFinetune.forward (model.py:121-139): (B, D, H, W) with H = W = int(L ** 0.5)."""
+    p = cfg["patch_size"]
+    t = patch_embed(sd, x, p)
+    B, L, D = t.shape
+    if mask is not None:
+        tok = mask_token.expand(B, L, -1)
+        w = mask.flatten(1).unsqueeze(-1).type_as(tok)
+        t = t * (1 - w) + tok * w
+    t = torch.cat((sd["cls_token"].expand(B, -1, -1), t), dim=1)
+    if img_size != 224:
+        t = t + interpolate_pos_encoding(sd, L, img_size, img_size, p)
+    else:
+        t = t + sd["pos_embed"]
+    for i in range(cfg["depth"]):
+        t = block(sd, cfg, i, t)[0]
+    t = layer_norm(sd, "norm", t, cfg["eps"])[:, 1:]
+    side = int(L ** 0.5)
+    return t.permute(0, 2, 1).reshape(B, D, side, side)
+
+
+def conv1x1_pixel_shuffle(z, weight, bias, stride):
+    """nn.Sequential(Conv2d(D, s*s*c, 1), PixelShuffle(s)) of model.py:60-66,147-152."""
+    return F.pixel_shuffle(F.conv2d(z, weight, bias), stride)
+
+
+def mim_forward(sd, cfg, x, mask, img_size, mask_token, dec_w, dec_b, stride, patch_size=8, in_chans=3):
+    """MIM.forward (model.py:68-74) -> (loss, x_rec, mask)."""
+    z = encoder_fmap(sd, cfg, x, img_size, mask=mask, mask_token=mask_token)
+    x_rec = conv1x1_pixel_shuffle(z, dec_w, dec_b, stride)
+    m = mask.repeat_interleave(patch_size, 1).repeat_interleave(patch_size, 2).unsqueeze(1).contiguous()
+    loss_recon = F.l1_loss(x, x_rec, reduction="none")
+    loss = (loss_recon * m).sum() / (m.sum() + 1e-5) / in_chans
+    return loss, x_rec, m

@@ -21,3 +21,11 @@ CASES = {
     "vitb16_384_full": dict(arch="vit_base", patch=16, img_size=224, variant="full", seed=0,
                             inputs=[(1, 384, 384, 99)], n=1),
 }
+
+
+# model.py wrappers: encoder geometry + decoder stride; weights / masks from synth.py.
+# img_size != 224 exercises the interpolated-position branch (model.py:38-39), 224 the native one.
+WRAPPER_CASES = {
+    "wrap_p8_64": dict(dim=128, depth=2, heads=2, patch=8, img_size=64, batch=2, seed=11, variant="full"),
+    "wrap_p16_224": dict(dim=128, depth=2, heads=2, patch=16, img_size=224, batch=1, seed=12, variant="sharp"),
+}

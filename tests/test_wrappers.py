@@ -1,0 +1,138 @@
+"""model.py wrappers: VisionTransformerForSimMIM / MIM / VisionTransformerForFinetune /
+LinearProbing. CPU: the oracle reproduces the fixtures written from the reference's own classes, and the
+mirror keeps the reference's constructor surface and state_dict keys. GPU: the product against the fixtures."""
+import types
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import vit_oracle as O
+from tests.golden_cases import WRAPPER_CASES
+from tests.helpers import load_golden
+from vit_ocm_wmsegmentation_amd import model as M
+from vit_ocm_wmsegmentation_amd import synth
+
+
+def _case(name):
+    c = WRAPPER_CASES[name]
+    sd = synth.synth_state_dict(c["dim"], c["depth"], c["patch"], seed=c["seed"], variant=c["variant"], img_size=224)
+    x = synth.synth_tiles(c["batch"], c["img_size"], seed=c["seed"] + 100)
+    mask = synth.synth_patch_mask(c["batch"], c["img_size"] // c["patch"], seed=c["seed"])
+    return c, sd, x, mask
+
+
+def _kw(c):
+    return dict(patch_size=c["patch"], embed_dim=c["dim"], depth=c["depth"], num_heads=c["heads"], mlp_ratio=4,
+                img_size=[c["img_size"]], qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+                interpolate_encoding=True)
+
+
+@pytest.mark.parametrize("name", sorted(WRAPPER_CASES))
+def test_oracle_reproduces_reference_wrappers(name):
+    c, sd, x, mask = _case(name)
+    g = load_golden("wrappers")
+    assert float(g["oracle_vs_reference_maxabs"]) == 0.0
+    cfg = O.make_cfg(sd, c["patch"], c["heads"])
+    p, S = c["patch"], c["img_size"]
+    wp1 = synth.synth_wrapper_params(c["dim"], p, 1, seed=c["seed"])
+    wp3 = synth.synth_wrapper_params(c["dim"], p, 3, seed=c["seed"])
+    z = O.encoder_fmap(sd, cfg, x, S)
+    assert np.abs(z.numpy() - g[name + "_fmap"]).max() <= 1e-6
+    rec1 = O.conv1x1_pixel_shuffle(z, wp1["decoder.weight"], wp1["decoder.bias"], p)
+    assert np.abs(rec1.numpy() - g[name + "_rec1"]).max() <= 1e-6
+    loss, rec3, _ = O.mim_forward(sd, cfg, x, mask, S, wp3["mask_token"], wp3["decoder.weight"], wp3["decoder.bias"], p,
+                                  patch_size=p)
+    assert np.abs(rec3.numpy() - g[name + "_rec3"]).max() <= 1e-6
+    assert abs(float(loss) - float(g[name + "_loss"])) <= 1e-6
+
+
+def test_wrapper_surface_and_state_dict_keys():
+    c = WRAPPER_CASES["wrap_p8_64"]
+    enc = M.VisionTransformerForSimMIM(**_kw(c))
+    assert enc.img_size == [64] and enc.interpolate_encoding is True and tuple(enc.mask_token.shape) == (1, 1, c["dim"])
+    assert float(enc.mask_token.detach().abs().max()) <= 0.02  # trunc_normal_(std=.02, a=-std, b=std), model.py:21-22
+    mim = M.MIM(enc, c["patch"])
+    keys = set(mim.state_dict())
+    assert {"encoder.mask_token", "encoder.cls_token", "encoder.pos_embed", "decoder.0.weight", "decoder.0.bias"} <= keys
+    assert tuple(mim.decoder[0].weight.shape) == (c["patch"] ** 2 * 3, c["dim"], 1, 1)
+    assert mim.in_chans == 3 and mim.patch_size == 8 and mim.no_weight_decay() == {}
+    fin = M.VisionTransformerForFinetune(**_kw(c))
+    lp = M.LinearProbing(fin, c["patch"], layer_num=1)
+    k2 = set(lp.state_dict())
+    assert {"one_layer_decoder.0.weight", "two_layer_decoder.0.weight", "two_layer_decoder.1.running_mean",
+            "two_layer_decoder.3.bias", "encoder.norm.weight"} <= k2
+    assert "mask_token" not in fin.state_dict()
+
+
+def test_wrapper_cpu_input_fails_loudly():
+    c = WRAPPER_CASES["wrap_p8_64"]
+    fin = M.VisionTransformerForFinetune(**_kw(c))
+    with pytest.raises(RuntimeError, match="HIP"):
+        fin(torch.zeros(1, 3, 64, 64))
+
+
+def test_build_functions_and_get_state_dict(tmp_path):
+    args = types.SimpleNamespace(MODEL=types.SimpleNamespace(PATCH_SIZE=8, NAME="vit_small"),
+                                 DATA=types.SimpleNamespace(IMG_SIZE=64), PRETRAINED_WEIGHTS=str(tmp_path / "w.pth"),
+                                 checkpoint_key="teacher")
+    enc = M.build_model(args)  # model.py:85-103: depth 4, 3 heads
+    assert len(enc.blocks) == 4 and enc.blocks[0].attn.num_heads == 3 and enc.img_size == [64]
+    with pytest.raises(FileNotFoundError):
+        M.get_state_dict(args)
+    sd = synth.synth_state_dict(384, 12, 8, seed=1, variant="init", img_size=224)
+    torch.save({"teacher": {"module.backbone." + k: v for k, v in sd.items()}}, args.PRETRAINED_WEIGHTS)
+    got = M.get_state_dict(args)
+    assert set(got) == set(sd)
+    fin = M.build_finetune_model(args)
+    assert torch.equal(fin.state_dict()["blocks.3.mlp.fc1.weight"], sd["blocks.3.mlp.fc1.weight"])
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("name", sorted(WRAPPER_CASES))
+def test_wrappers_match_reference_fixtures(dev, name, precision, tol):
+    """Encoders and decoders of model.py on the HIP path against the outputs of the reference's own classes.
+    fp32 mode: round-off; bf16 mode: the (B,C,H,W) features are O(1) LayerNorm outputs, tolerance 3e-2 abs."""
+    c, sd, x, mask = _case(name)
+    g = load_golden("wrappers")
+    p = c["patch"]
+    wp1 = synth.synth_wrapper_params(c["dim"], p, 1, seed=c["seed"])
+    wp3 = synth.synth_wrapper_params(c["dim"], p, 3, seed=c["seed"])
+    fin = M.VisionTransformerForFinetune(**_kw(c))
+    assert not fin.load_state_dict(sd, strict=True).missing_keys
+    fin = fin.to(dev).eval().set_precision(precision)
+    z = fin(x.to(dev))
+    assert tuple(z.shape) == g[name + "_fmap"].shape
+    assert np.abs(z.cpu().numpy() - g[name + "_fmap"]).max() <= tol
+    lp = M.LinearProbing(fin, p).to(dev).eval()
+    lp.one_layer_decoder[0].weight.data.copy_(wp1["decoder.weight"])
+    lp.one_layer_decoder[0].bias.data.copy_(wp1["decoder.bias"])
+    rec1 = lp(x.to(dev))
+    assert tuple(rec1.shape) == g[name + "_rec1"].shape
+    assert np.abs(rec1.cpu().numpy() - g[name + "_rec1"]).max() <= tol
+
+    enc = M.VisionTransformerForSimMIM(**_kw(c))
+    assert not enc.load_state_dict(dict(sd, mask_token=wp3["mask_token"]), strict=True).missing_keys
+    enc = enc.to(dev).eval().set_precision(precision)
+    zm = enc(x.to(dev), mask.to(dev))
+    assert np.abs(zm.cpu().numpy() - g[name + "_fmap_masked"]).max() <= tol
+    mim = M.MIM(enc, p).to(dev).eval()
+    mim.patch_size = p
+    mim.decoder[0].weight.data.copy_(wp3["decoder.weight"])
+    mim.decoder[0].bias.data.copy_(wp3["decoder.bias"])
+    loss, rec3, mup = mim(x.to(dev), mask)
+    assert np.abs(rec3.cpu().numpy() - g[name + "_rec3"]).max() <= tol
+    assert abs(float(loss) - float(g[name + "_loss"])) <= tol
+    assert tuple(mup.shape) == (c["batch"], 1, c["img_size"], c["img_size"])
+
+
+@pytest.mark.gpu
+def test_reference_mim_head_dim_128_is_a_documented_gap(dev):
+    args = types.SimpleNamespace(MODEL=types.SimpleNamespace(PATCH_SIZE=8), DATA=types.SimpleNamespace(IMG_SIZE=64))
+    enc = M.build_model(args).to(dev).eval()
+    with pytest.raises(ValueError, match="head_dim"):
+        enc(torch.zeros(1, 3, 64, 64, device=dev), torch.zeros(1, 8, 8, dtype=torch.int64, device=dev))

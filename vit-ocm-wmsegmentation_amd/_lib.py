@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OCM_VIT_LIB lets kernel experiments A/B two builds of the same ABI; the default is the in-tree build.
 LIB_PATH = os.environ.get("OCM_VIT_LIB") or os.path.join(_HERE, "libocm_vit.so")
 
-OCM_ABI_VERSION = 2
+OCM_ABI_VERSION = 3
 OCM_OK, OCM_EINVAL, OCM_ESTATE, OCM_EHIP, OCM_ENOMEM, OCM_ENAME = 0, 1, 2, 3, 4, 5
 
 OCM_PREC_BF16 = 0
@@ -23,6 +23,7 @@ OCM_OUT_QKV = 1 << 2
 OCM_OUT_TOKENS = 1 << 3
 OCM_OUT_ROWS = 1 << 4
 OCM_LAST_ATTN_ONLY = 1 << 5
+OCM_OUT_FMAP = 1 << 6
 
 KERNEL_CLASSES = ("patch_embed", "layernorm", "qkv_gemm", "attention", "attn_probs", "proj_gemm", "fc1_gemm",
                   "fc2_gemm")
@@ -69,6 +70,8 @@ class OcmVitIO(C.Structure):
         ("n_rows", C.c_int32),
         ("reserved", C.c_int32),
         ("out_rows", C.c_void_p),
+        ("patch_mask", C.c_void_p),
+        ("out_fmap", C.c_void_p),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_size_t),
         ("stream", C.c_void_p),
@@ -104,6 +107,7 @@ SIGNATURES = {
     "ocm_op_normalize_u8": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ocm_otsu_threshold": (_i32, [C.POINTER(C.c_uint64), _i64]),
     "ocm_op_threshold_u8": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "ocm_op_pixel_shuffle": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_head_mean": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_image_to_gray_u8": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "ocm_op_blend_u8": (C.c_int, [_vp, _vp, _i64, C.c_double, C.c_double, _vp, _vp, _vp]),

@@ -109,6 +109,7 @@ struct Param {
     size_t count;   // elements in the reference tensor
     size_t offset;  // bytes into the arena
     bool set;
+    bool optional = false;  // not required by ocm_vit_params_ready (mask_token)
 };
 
 struct BlockP {
@@ -122,7 +123,7 @@ struct ocm_vit {
     size_t esz;
     std::vector<Param> params;
     std::vector<BlockP> blk;
-    int cls, pe_w, pe_b, norm_g, norm_b;
+    int cls, pe_w, pe_b, norm_g, norm_b, mask_tok;
     char *arena;
     size_t arena_bytes;
 
@@ -183,6 +184,8 @@ extern "C" int ocm_vit_create(const ocm_vit_config *cfg, ocm_vit_t **out) {
     }
     h->norm_g = h->add("norm.weight", P_F32, d, d);
     h->norm_b = h->add("norm.bias", P_F32, d, d);
+    h->mask_tok = h->add("mask_token", P_F32, d, d);
+    h->params[h->mask_tok].optional = true;
     hipError_t e = hipMalloc((void **)&h->arena, h->arena_bytes);
     if (e != hipSuccess) {
         const size_t bytes = h->arena_bytes;
@@ -241,7 +244,7 @@ extern "C" int ocm_vit_set_param(ocm_vit_t *h, const char *name, const float *de
 extern "C" int ocm_vit_params_ready(const ocm_vit_t *h) {
     if (!h) return fail(OCM_EINVAL, "null handle");
     for (const Param &pr : h->params)
-        if (!pr.set) return fail(OCM_ESTATE, "parameter '%s' has not been set", pr.name.c_str());
+        if (!pr.set && !pr.optional) return fail(OCM_ESTATE, "parameter '%s' has not been set", pr.name.c_str());
     return OCM_OK;
 }
 
@@ -343,6 +346,11 @@ static int check_tiles(const ocm_vit *h, const ocm_vit_io *io, int *n_out) {
 static int run_prepare(const ocm_vit *h, const ocm_vit_io *io, float *x, int n, hipStream_t s) {
     PatchArgs pa{io->image, io->img_stride_b, io->img_stride_c, io->img_stride_y, io->tile_origins,
                  io->batch, io->tile_h / h->p, io->tile_w / h->p, h->p, h->C};
+    if (io->patch_mask) {
+        if (!h->params[h->mask_tok].set) return fail(OCM_ESTATE, "patch_mask given but parameter 'mask_token' has not been set");
+        pa.mask = io->patch_mask;
+        pa.mask_tok = h->ptr<float>(h->mask_tok);
+    }
     HIP_TRY(launch_cls_rows(h->ptr<float>(h->cls), io->pos_embed, x, io->batch, n, h->D, s));
     PROF(OCM_K_PATCH, s);
     HIP_TRY(launch_patch_embed(h->prec, pa, h->ptr<char>(h->pe_w), h->ptr<float>(h->pe_b), io->pos_embed, x, h->D, s));
@@ -393,8 +401,11 @@ extern "C" int ocm_vit_forward(ocm_vit_t *h, const ocm_vit_io *io) {
     const int fl = io->flags, B = io->batch, L = h->L;
     const bool attn_only = fl & OCM_LAST_ATTN_ONLY;
     if (io->n_last < 1 || io->n_last > L) return fail(OCM_EINVAL, "n_last %d out of range [1,%d]", io->n_last, L);
-    if (attn_only && (fl & (OCM_OUT_FEAT | OCM_OUT_TOKENS | OCM_OUT_QKV)))
-        return fail(OCM_EINVAL, "OCM_LAST_ATTN_ONLY excludes FEAT/TOKENS/QKV outputs");
+    if (attn_only && (fl & (OCM_OUT_FEAT | OCM_OUT_TOKENS | OCM_OUT_QKV | OCM_OUT_FMAP)))
+        return fail(OCM_EINVAL, "OCM_LAST_ATTN_ONLY excludes FEAT/TOKENS/QKV/FMAP outputs");
+    if ((fl & OCM_OUT_FMAP) && !io->out_fmap) return fail(OCM_EINVAL, "OCM_OUT_FMAP without out_fmap");
+    if ((fl & OCM_OUT_FMAP) && (size_t)h->M * h->esz < (size_t)h->D * 4)
+        return fail(OCM_EINVAL, "OCM_OUT_FMAP needs mlp_hidden*esz >= 4*embed_dim (scratch for the normed tokens)");
     if (attn_only && io->n_last != 1) return fail(OCM_EINVAL, "OCM_LAST_ATTN_ONLY requires n_last == 1");
     if ((fl & OCM_OUT_FEAT) && !io->out_feat) return fail(OCM_EINVAL, "OCM_OUT_FEAT without out_feat");
     if ((fl & OCM_OUT_ATTN) && !io->out_attn) return fail(OCM_EINVAL, "OCM_OUT_ATTN without out_attn");
@@ -423,6 +434,12 @@ extern "C" int ocm_vit_forward(ocm_vit_t *h, const ocm_vit_io *io) {
     }
     if (fl & OCM_OUT_TOKENS)
         HIP_TRY(hipMemcpyAsync(io->out_tokens, w.x, T * h->D * 4, hipMemcpyDeviceToDevice, s));
+    if (fl & OCM_OUT_FMAP) {  // norm(x)[:, 1:] -> (B, D, hp, wp); the hidden-activation buffer is free by now
+        float *yn = (float *)w.hid;
+        HIP_TRY(launch_layernorm(w.x, h->ptr<float>(h->norm_g), h->ptr<float>(h->norm_b), yn, false, T, h->D,
+                                 h->cfg.ln_eps, s));
+        HIP_TRY(launch_tokens_to_fmap(yn, io->out_fmap, B, n, h->D, s));
+    }
     return OCM_OK;
 }
 
@@ -575,6 +592,14 @@ extern "C" int ocm_op_blend_u8(const uint8_t *img, const uint8_t *att, int64_t c
     if (count <= 0) return fail(OCM_EINVAL, "bad count");
     HIP_TRY(launch_blend_u8(img, att, (size_t)count, alpha, one_minus_alpha, out, (unsigned long long *)hist256,
                             (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_pixel_shuffle(const float *lin, float *out, int32_t batch, int32_t hp, int32_t wp, int32_t c_out,
+                                    int32_t sh, void *stream) {
+    if (!lin || !out) return fail(OCM_EINVAL, "null argument");
+    if (batch <= 0 || hp <= 0 || wp <= 0 || c_out <= 0 || sh <= 0) return fail(OCM_EINVAL, "bad shape");
+    HIP_TRY(launch_pixel_shuffle(lin, out, batch, hp, wp, c_out, sh, (hipStream_t)stream));
     return OCM_OK;
 }
 

@@ -342,10 +342,13 @@ struct PatchLoader {
 };
 
 // x[b][1 + pi][n] = acc + pos[1 + pi][n]   (prepare_tokens :200-207, patch rows; bias is in acc)
+// With a SimMIM mask (model.py:28-33) the patch row is first blended with the mask token:
+// acc*(1-w) + mask_token*w, w = mask[b][pi], evaluated in that order in fp32.
 struct EpiPatch {
     const float *bias, *pos;
     float *x;
     int M, P, ntok, D;
+    const float *mask, *mask_tok;
     template <class Cfg>
     __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, CPR = BN / 4;
@@ -355,7 +358,14 @@ struct EpiPatch {
             const int m = m0 + row, n = n0 + col;
             if (m >= M || n >= D) continue;
             const int b = m / P, t = m - b * P;
-            const f32x4 v = *(const f32x4 *)(C + row * BN + col) + *(const f32x4 *)(pos + (int64_t)(1 + t) * D + n);
+            f32x4 v = *(const f32x4 *)(C + row * BN + col);
+            if (mask) {
+                const float w = mask[m], omw = 1.0f - w;
+                const f32x4 tk = *(const f32x4 *)(mask_tok + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * omw + tk[e] * w;  // exact for the 0/1 masks SimMIM draws
+            }
+            v += *(const f32x4 *)(pos + (int64_t)(1 + t) * D + n);
             *(f32x4 *)(x + ((int64_t)b * ntok + 1 + t) * D + n) = v;
         }
     }
@@ -366,7 +376,7 @@ static hipError_t launch_patch_e(const PatchArgs &pa, const E *w, const float *b
                                  hipStream_t s) {
     const int P = pa.hp * pa.wp, M = pa.batch * P, K = pa.chans * pa.p * pa.p;
     PatchLoader<E> al{pa.image, pa.sb, pa.sc, pa.sy, pa.origins, P, pa.wp, pa.p, pa.p * pa.p};
-    EpiPatch epi{bias, pos, x, M, P, P + 1, dim};
+    EpiPatch epi{bias, pos, x, M, P, P + 1, dim, pa.mask, pa.mask_tok};
     if (dim % 128 == 0 && M > 64) return launch_gemm<Cfg64x128, E, false>(al, w, K, M, dim, K, epi, s);
     return launch_gemm<Cfg64x64, E, false>(al, w, K, M, dim, K, epi, s);
 }

@@ -214,3 +214,53 @@ hipError_t launch_cls_rows(const float *cls, const float *pos, float *x, int bat
     cls_rows_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(cls, pos, x, batch, n_tokens, dim);
     return hipGetLastError();
 }
+
+// ---- encoders of model.py:48-53,134-139: x[:, 1:].permute(0, 2, 1).reshape(B, C, H, W) ----
+// y: (B, N, D) normed tokens; out: (B, D, N-1). 32x32 tiles through LDS so that both sides are coalesced.
+__global__ __launch_bounds__(256) void tokens_to_fmap_kernel(const float *__restrict__ y, float *__restrict__ out,
+                                                             int N, int D) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int P = N - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int t = t0 + ty + 8 * i;
+        if (t < P) tile[ty + 8 * i][tx] = y[((size_t)b * N + 1 + t) * D + d0 + tx];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int d = d0 + ty + 8 * i, t = t0 + tx;
+        if (t < P) out[((size_t)b * D + d) * P + t] = tile[tx][ty + 8 * i];
+    }
+}
+
+hipError_t launch_tokens_to_fmap(const float *y, float *out, int batch, int n_tokens, int dim, hipStream_t s) {
+    const dim3 grid((n_tokens - 1 + 31) / 32, dim / 32, batch);
+    tokens_to_fmap_kernel<<<grid, dim3(256), 0, s>>>(y, out, n_tokens, dim);
+    return hipGetLastError();
+}
+
+// ---- nn.PixelShuffle(s) of a token-major 1x1 conv (model.py:60-66): one thread per output pixel quad ----
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float *__restrict__ lin, float *__restrict__ out,
+                                                            int hp, int wp, int c_out, int sh, size_t total) {
+    const int Hs = hp * sh, Ws = wp * sh, O = c_out * sh * sh;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int xo = (int)(i % Ws);
+        size_t r = i / Ws;
+        const int yo = (int)(r % Hs);
+        r /= Hs;
+        const int c = (int)(r % c_out), b = (int)(r / c_out);
+        const int y = yo / sh, ii = yo - y * sh, x = xo / sh, jj = xo - x * sh;
+        out[i] = lin[((size_t)b * hp * wp + (size_t)y * wp + x) * O + (c * sh + ii) * sh + jj];
+    }
+}
+
+hipError_t launch_pixel_shuffle(const float *lin, float *out, int batch, int hp, int wp, int c_out, int sh, hipStream_t s) {
+    const size_t total = (size_t)batch * c_out * hp * sh * wp * sh;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    pixel_shuffle_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(lin, out, hp, wp, c_out, sh, total);
+    return hipGetLastError();
+}

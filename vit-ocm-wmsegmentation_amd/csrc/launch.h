@@ -25,6 +25,8 @@ struct PatchArgs {
     int64_t sb, sc, sy;
     const int32_t *origins;
     int batch, hp, wp, p, chans;  // hp x wp patches per tile
+    const float *mask = nullptr;      // [B][P] SimMIM mask weights or null (model.py:28-33)
+    const float *mask_tok = nullptr;  // [D]
 };
 hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, const float *bias, const float *pos,
                               float *x, int dim, hipStream_t s);
@@ -48,6 +50,8 @@ hipError_t launch_stitch(const float *crops, float *out, const double *ramp, int
 hipError_t launch_normalize_u8(const float *img, size_t count, float *part, uint8_t *out,
                                unsigned long long *hist256, hipStream_t s);
 hipError_t launch_threshold_u8(const uint8_t *img, uint8_t *mask, size_t count, int thresh, hipStream_t s);
+hipError_t launch_tokens_to_fmap(const float *y, float *out, int batch, int n_tokens, int dim, hipStream_t s);
+hipError_t launch_pixel_shuffle(const float *lin, float *out, int batch, int hp, int wp, int c_out, int sh, hipStream_t s);
 hipError_t launch_head_mean(const float *rows, float *maps, int tiles, int heads, int n_rows, int pixels, hipStream_t s);
 hipError_t launch_image_to_gray_u8(const float *img, int64_t stride_c, int chans, size_t count, uint8_t *out,
                                    unsigned long long *hist256, hipStream_t s);

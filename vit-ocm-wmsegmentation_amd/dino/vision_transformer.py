@@ -274,7 +274,7 @@ class VisionTransformer(nn.Module):
         return self
 
     def _named_engine_params(self):
-        skip = ("pos_embed", "head.", "mask_token")
+        skip = ("pos_embed", "head.")
         return [(n, p) for n, p in self.named_parameters() if not n.startswith(skip)]
 
     def _engine(self, device):

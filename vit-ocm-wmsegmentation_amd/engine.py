@@ -9,7 +9,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (OCM_LAST_ATTN_ONLY, OCM_OUT_ATTN, OCM_OUT_FEAT, OCM_OUT_QKV, OCM_OUT_ROWS,
+from ._lib import (OCM_LAST_ATTN_ONLY, OCM_OUT_ATTN, OCM_OUT_FEAT, OCM_OUT_FMAP, OCM_OUT_QKV, OCM_OUT_ROWS,
                    OCM_OUT_TOKENS, OcmVitConfig, OcmVitIO, check)
 
 
@@ -90,7 +90,7 @@ class Engine:
         return io
 
     def forward_tiles(self, image, strides, origins, batch, tile_h, tile_w, pos, *, flags, n_last=1,
-                      query_rows=None):
+                      query_rows=None, patch_mask=None):
         """One ocm_vit_forward. `image` is an fp32 HIP tensor holding the planes, `strides`
         = (batch, channel, row) element strides, `origins` an int32 (B,2) HIP tensor or None.
         Returns a dict with the requested outputs (fresh tensors)."""
@@ -127,6 +127,15 @@ class Engine:
                 out["rows"] = torch.empty((B, H, query_rows.numel(), n - 1), **kw)
                 io.query_rows, io.n_rows = query_rows.data_ptr(), query_rows.numel()
                 io.out_rows = out["rows"].data_ptr()
+            if flags & OCM_OUT_FMAP:
+                out["fmap"] = torch.empty((B, D, tile_h // self.p, tile_w // self.p), **kw)
+                io.out_fmap = out["fmap"].data_ptr()
+            if patch_mask is not None:
+                _require_hip(patch_mask, "mask")
+                patch_mask = patch_mask.reshape(B, -1).to(torch.float32).contiguous()
+                if patch_mask.shape[1] != n - 1:
+                    raise ValueError(f"mask has {patch_mask.shape[1]} entries per image, expected {n - 1}")
+                io.patch_mask = patch_mask.data_ptr()
             io.workspace, io.workspace_bytes = self.workspace(B, n)
             check(self.lib.ocm_vit_forward(self._h, C.byref(io)))
         return out

@@ -1,0 +1,223 @@
+"""Mirror of the reference's model.py wrappers around the ViT trunk:
+
+  VisionTransformerForSimMIM    model.py:10-53    patch embed -> mask-token blend -> trunk -> (B,C,H,W)
+  MIM                           model.py:55-83    encoder + Conv2d(1x1) + PixelShuffle decoder, masked L1 loss
+  VisionTransformerForFinetune  model.py:110-139  trunk -> (B,C,H,W)
+  LinearProbing                 model.py:142-174  encoder + one-layer (1x1 conv + PixelShuffle) decoder
+  build_model / build_finetune_model / get_state_dict   model.py:85-108,176-226
+
+Same constructor arguments, attributes and state_dict keys. The encoders run in one engine call (the mask
+blend is fused into the patch-embedding epilogue, the (B,C,H,W) permute is a device transpose); the 1x1-conv
+decoders run token-major as one MFMA GEMM + a pixel-shuffle kernel. Inference only: parameters are read,
+never differentiated. The reference initialises mask_token with timm's trunc_normal_; here the package's
+own trunc_normal_ (dino/utils.py) with the same bounds is used.
+"""
+import ctypes as C
+import os
+from functools import partial
+
+import torch
+import torch.nn as nn
+from torch.nn import functional as F
+
+from . import _lib
+from .dino.utils import trunc_normal_
+from .dino.vision_transformer import VisionTransformer
+from .engine import _p, _require_hip, _stream
+
+
+class _FmapEncoder(VisionTransformer):
+    """Shared body of the two encoders: prepare tokens (optionally masked), all blocks, final norm, drop the
+    CLS token and return the (B, C, H, W) map."""
+
+    def _encode(self, x, mask=None, tokens=False):
+        x = self._check_input(x)
+        eng = self._engine(x.device)
+        npatch = (x.shape[-2] // eng.p) * (x.shape[-1] // eng.p)
+        side = self.img_size[0]
+        if side != 224:  # model.py:38-39,124-125: positions interpolated for the CONFIGURED size
+            pos = self._pos_for(npatch, side, side, x.device)
+        else:  # model.py:40-41,126-127: x + self.pos_embed needs the native token count
+            n0 = self.pos_embed.shape[1] - 1
+            if npatch != n0:
+                raise RuntimeError(f"The size of tensor a ({npatch + 1}) must match the size of tensor b ({n0 + 1}) "
+                                   "at non-singleton dimension 1")
+            pos = self._pos_for(n0, 224, 224, x.device)
+        flags = _lib.OCM_OUT_FEAT if tokens else _lib.OCM_OUT_FMAP
+        out = eng.forward(x, pos, flags=flags, patch_mask=mask)
+        if tokens:
+            return out["feat"][0]
+        fmap = out["fmap"]
+        B, Cc, hp, wp = fmap.shape
+        side_t = int((hp * wp) ** 0.5)  # model.py:50-52: H = W = int(L ** 0.5)
+        return fmap.reshape(B, Cc, side_t, side_t)
+
+
+class VisionTransformerForSimMIM(_FmapEncoder):
+    def __init__(self, interpolate_encoding=False, img_size=224, **kwargs):
+        super().__init__(**kwargs)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, self.embed_dim))
+        self.img_size = img_size
+        self._trunc_normal_(self.mask_token, std=.02)
+        self.interpolate_encoding = interpolate_encoding
+
+    def _trunc_normal_(self, tensor, mean=0., std=1.):
+        trunc_normal_(tensor, mean=mean, std=std, a=-std, b=std)
+
+    def forward(self, x, mask):
+        assert mask is not None
+        return self._encode(x, mask=mask.to(x.device))
+
+
+class VisionTransformerForFinetune(_FmapEncoder):
+    def __init__(self, interpolate_encoding=False, img_size=224, **kwargs):
+        super().__init__(**kwargs)
+        self.img_size = img_size
+        self.interpolate_encoding = interpolate_encoding
+
+    def _trunc_normal_(self, tensor, mean=0., std=1.):
+        trunc_normal_(tensor, mean=mean, std=std, a=-std, b=std)
+
+    def forward(self, x):
+        return self._encode(x)
+
+
+def _conv1x1_pixel_shuffle(encoder, tokens, conv, stride, cache):
+    """Conv2d(D, s*s*c, 1) + PixelShuffle(s) evaluated on the token-major normed tokens (B, N, D): one GEMM over
+    the patch rows and a scatter. Returns (B, c, hp*s, wp*s) fp32."""
+    B, N, D = tokens.shape
+    O = conv.out_channels
+    c_out = O // (stride * stride)
+    hp = wp = int((N - 1) ** 0.5)
+    prec = _lib.PRECISIONS[encoder._precision]
+    dev = tokens.device
+    lib = _lib.load()
+    key = (conv.weight.data_ptr(), conv.weight._version, prec)
+    if cache.get("key") != key:  # operand copy of the (O, D, 1, 1) weight in the engine's element type
+        w32 = conv.weight.detach().reshape(O, D).to(device=dev, dtype=torch.float32).contiguous()
+        if prec == _lib.OCM_PREC_BF16:
+            w = torch.empty((O, D), dtype=torch.bfloat16, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.ocm_op_cast_bf16(_p(w32), _p(w), w32.numel(), _stream()))
+        else:
+            w = w32
+        bias = (conv.bias.detach() if conv.bias is not None else torch.zeros(O)).to(device=dev, dtype=torch.float32)
+        cache.update(key=key, w=w, bias=bias.contiguous())
+    patches = tokens[:, 1:].contiguous()  # (B, P, D) fp32: drop the CLS row
+    M = B * (N - 1)
+    lin = torch.empty((M, O), dtype=torch.float32, device=dev)
+    out = torch.empty((B, c_out, hp * stride, wp * stride), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        if prec == _lib.OCM_PREC_BF16:
+            a = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.ocm_op_cast_bf16(_p(patches), _p(a), patches.numel(), _stream()))
+        else:
+            a = patches
+        _lib.check(lib.ocm_op_linear(prec, _p(a), _p(cache["w"]), _p(cache["bias"]), None, _p(lin), M, O, D,
+                                     _lib.OCM_EPI_BIAS_F32, _stream()))
+        _lib.check(lib.ocm_op_pixel_shuffle(_p(lin), _p(out), B, hp, wp, c_out, stride, _stream()))
+    return out
+
+
+class MIM(nn.Module):
+    def __init__(self, encoder, encoder_stride):
+        super().__init__()
+        self.encoder = encoder
+        self.encoder_stride = encoder_stride
+        self.decoder = nn.Sequential(
+            nn.Conv2d(in_channels=self.encoder.num_features, out_channels=self.encoder_stride ** 2 * 3, kernel_size=1),
+            nn.PixelShuffle(self.encoder_stride),
+        )
+        self.in_chans = 3
+        self.patch_size = 8
+        self.__dict__["_dec_cache"] = {}
+
+    @torch.no_grad()
+    def forward(self, x, mask):
+        _require_hip(x, "input")
+        tokens = self.encoder._encode(x, mask=mask.to(x.device), tokens=True)
+        x_rec = _conv1x1_pixel_shuffle(self.encoder, tokens, self.decoder[0], self.encoder_stride, self._dec_cache)
+        # the masked L1 loss (model.py:71-73) is training bookkeeping: a handful of elementwise torch ops
+        mask = mask.to(x.device).repeat_interleave(self.patch_size, 1).repeat_interleave(self.patch_size, 2).unsqueeze(1).contiguous()
+        loss_recon = F.l1_loss(x, x_rec, reduction='none')
+        loss = (loss_recon * mask).sum() / (mask.sum() + 1e-5) / self.in_chans
+        return loss, x_rec, mask
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        if hasattr(self.encoder, 'no_weight_decay'):
+            return {'encoder.' + i for i in self.encoder.no_weight_decay()}
+        return {}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        if hasattr(self.encoder, 'no_weight_decay_keywords'):
+            return {'encoder.' + i for i in self.encoder.no_weight_decay_keywords()}
+        return {}
+
+
+class LinearProbing(nn.Module):
+    def __init__(self, encoder, encoder_stride, layer_num=1):
+        super().__init__()
+        self.encoder = encoder
+        self.layer_num = layer_num
+        self.encoder_stride = encoder_stride
+        self.one_layer_decoder = nn.Sequential(
+            nn.Conv2d(in_channels=self.encoder.num_features, out_channels=self.encoder_stride ** 2, kernel_size=1),
+            nn.PixelShuffle(self.encoder_stride),
+        )
+        self.two_layer_decoder = nn.Sequential(
+            nn.Conv2d(in_channels=self.encoder.num_features, out_channels=self.encoder_stride ** 2 * 4, kernel_size=3,
+                      padding=1),
+            nn.BatchNorm2d(self.encoder_stride ** 2 * 4),
+            nn.ReLU(inplace=True),
+            nn.Conv2d(in_channels=self.encoder_stride ** 2 * 4, out_channels=self.encoder_stride ** 2, kernel_size=3,
+                      padding=1),
+            nn.PixelShuffle(self.encoder_stride),
+        )
+        self.__dict__["_dec_cache"] = {}
+
+    @torch.no_grad()
+    def forward(self, x):
+        _require_hip(x, "input")
+        if self.layer_num == 2:
+            # 3x3 conv + BatchNorm head: not on the hot path (SURVEY §8-f row 3 names the 1x1 head); it runs as the
+            # torch modules the reference builds, on the encoder's feature map
+            return self.two_layer_decoder(self.encoder(x))
+        tokens = self.encoder._encode(x, tokens=True)
+        return _conv1x1_pixel_shuffle(self.encoder, tokens, self.one_layer_decoder[0], self.encoder_stride,
+                                      self._dec_cache)
+
+
+def build_model(args):
+    """model.py:85-103. NOTE: the reference's MIM encoder is depth 4 with 3 heads of 128 channels; the engine's
+    attention kernels are built for 64-channel heads, so this configuration raises ValueError at its first
+    forward (documented gap; every DINO-shaped encoder — 64-channel heads — runs)."""
+    return VisionTransformerForSimMIM(patch_size=args.MODEL.PATCH_SIZE, embed_dim=384, depth=4, num_heads=3,
+                                      mlp_ratio=4, img_size=[args.DATA.IMG_SIZE], qkv_bias=True,
+                                      norm_layer=partial(nn.LayerNorm, eps=1e-6), interpolate_encoding=True)
+
+
+def build_finetune_model(args):
+    encoder = VisionTransformerForFinetune(patch_size=args.MODEL.PATCH_SIZE, embed_dim=384, depth=12, num_heads=6,
+                                           mlp_ratio=4, img_size=[args.DATA.IMG_SIZE], qkv_bias=True,
+                                           norm_layer=partial(nn.LayerNorm, eps=1e-6), interpolate_encoding=True)
+    state_dict = get_state_dict(args)
+    encoder.load_state_dict(state_dict, strict=False)
+    return encoder
+
+
+def get_state_dict(args):
+    """model.py:190-226: a local checkpoint file is loaded (weights_only) and its `module.` / `backbone.`
+    prefixes stripped. The reference's fallback downloads DINO weights from dl.fbaipublicfiles.com; there is
+    no network on this path, so a missing file is an error."""
+    if os.path.isfile(args.PRETRAINED_WEIGHTS):
+        state_dict = torch.load(args.PRETRAINED_WEIGHTS, map_location="cpu", weights_only=True)
+        key = getattr(args, "checkpoint_key", None)
+        if key is not None and key in state_dict:
+            state_dict = state_dict[key]
+        state_dict = {k.replace("module.", ""): v for k, v in state_dict.items()}
+        state_dict = {k.replace("backbone.", ""): v for k, v in state_dict.items()}
+        return state_dict
+    raise FileNotFoundError(f"pretrained weights {args.PRETRAINED_WEIGHTS!r} not found (the reference would download "
+                            "DINO weights here; no network on this path)")

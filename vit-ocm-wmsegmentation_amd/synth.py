@@ -106,3 +106,20 @@ def synth_tiles(batch, height, width=None, *, seed=1234, channels=3):
     g = torch.Generator().manual_seed(seed)
     x1 = torch.rand(batch, 1, height, width, generator=g) * 0.3
     return x1.expand(-1, channels, -1, -1).contiguous() if channels > 1 else x1
+
+
+def synth_wrapper_params(embed_dim, stride, out_mult, *, seed=0):
+    """Extra parameters of the model.py wrappers: the SimMIM mask token (1,1,D) and the
+    1x1-conv decoder Conv2d(D, stride^2 * out_mult, 1) (out_mult = 3 for MIM, 1 for LinearProbing)."""
+    O = stride * stride * out_mult
+    return {
+        "mask_token": _normal(seed, "mask_token", (1, 1, embed_dim), 0.02),
+        "decoder.weight": _uniform(seed, f"decoder{out_mult}.weight", (O, embed_dim, 1, 1), 1.0 / np.sqrt(embed_dim)),
+        "decoder.bias": _uniform(seed, f"decoder{out_mult}.bias", (O,), 1.0 / np.sqrt(embed_dim)),
+    }
+
+
+def synth_patch_mask(batch, side, *, seed=7, ratio=0.6):
+    """SimMIM-style 0/1 patch mask (B, side, side) int64 with about `ratio` of the patches masked."""
+    v = _rng(seed, "patch_mask").uniform(0, 1, size=(batch, side, side))
+    return torch.from_numpy((v < ratio).astype(np.int64))
