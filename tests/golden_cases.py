@@ -29,3 +29,13 @@ WRAPPER_CASES = {
     "wrap_p8_64": dict(dim=128, depth=2, heads=2, patch=8, img_size=64, batch=2, seed=11, variant="full"),
     "wrap_p16_224": dict(dim=128, depth=2, heads=2, patch=16, img_size=224, batch=1, seed=12, variant="sharp"),
 }
+
+
+# Swin: fixtures come from the installed transformers package (oracle/make_golden_swin.py).
+# "tiny224" is the reference's configuration (SwinConfig defaults, num_labels=5, ADB/train.py:70-77);
+# "small56" is a 2-stage miniature (image 56 -> 14x14 -> 7x7 grids) that exercises shift masks and the
+# window-equals-grid clamp in seconds.
+SWIN_CASES = {
+    "tiny224": dict(batch=2, seed=21, qk_gain=6.0),
+    "small56": dict(batch=3, seed=22, qk_gain=6.0, cfg=dict(image_size=56, depths=(2, 2), num_heads=(3, 6))),
+}

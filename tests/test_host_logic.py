@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_library_exports_every_declared_symbol(lib):
-    header = open(os.path.join(ROOT, "include", "ocm_vit.h")).read()
+    header = open(os.path.join(ROOT, "include", "ocm_vit.h")).read() + open(os.path.join(ROOT, "include", "ocm_swin.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"\b(ocm_[a-z0-9_]+)\s*\(", header))
     assert len(declared) >= 20

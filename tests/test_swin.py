@@ -1,0 +1,131 @@
+"""Swin-T (BASELINE config 5). CPU: the oracle reproduces the fixtures written from the installed
+transformers package, the mirror keeps its state_dict keys. GPU: the product against the fixtures and the stand-alone
+(shifted-)window attention against the oracle's window arithmetic."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import swin_oracle as SO
+from tests.golden_cases import SWIN_CASES
+from tests.helpers import load_golden
+from vit_ocm_wmsegmentation_amd import _lib, synth
+from vit_ocm_wmsegmentation_amd import swin as SW
+
+
+def _case(name):
+    c = SWIN_CASES[name]
+    cfg = dict(synth.SWIN_TINY, **c.get("cfg", {}))
+    sd = synth.synth_swin_state_dict(cfg, seed=c["seed"], qk_gain=c["qk_gain"])
+    x = synth.synth_tiles(c["batch"], cfg["image_size"], seed=c["seed"] + 50)
+    return c, cfg, sd, x
+
+
+@pytest.mark.parametrize("name", ["small56"])
+def test_oracle_reproduces_transformers_fixture(name):
+    c, cfg, sd, x = _case(name)
+    g = load_golden("swin_" + name)
+    assert float(g["oracle_vs_transformers_maxabs"]) <= 2e-5
+    o = SO.swin_forward(sd, cfg, x)
+    assert np.abs(o["logits"].numpy() - g["logits"]).max() <= 2e-5
+    assert np.abs(o["pooled"].numpy() - g["pooled"]).max() <= 2e-5
+    for s, t in enumerate(o["stage_out"]):
+        assert np.abs(t[:, :4, :32].numpy() - g[f"stage{s}_head"]).max() <= 2e-5
+
+
+def test_mirror_keeps_transformers_state_dict_keys():
+    cfg = SW.SwinConfig(num_labels=5)
+    m = SW.SwinForImageClassification(cfg)
+    keys = set(m.state_dict())
+    assert keys == set(synth.swin_param_shapes(synth.SWIN_TINY))
+    assert "swin.encoder.layers.2.blocks.5.attention.relative_position_bias.relative_position_bias_table" in keys
+    sd = synth.synth_swin_state_dict(synth.SWIN_TINY, seed=3)
+    msg = m.load_state_dict(sd, strict=True)
+    assert not msg.missing_keys and not msg.unexpected_keys
+    assert torch.equal(m.state_dict()["classifier.weight"], sd["classifier.weight"])
+    assert cfg.hidden_size == 768 and m.num_labels == 5
+    with pytest.raises(RuntimeError, match="HIP"):
+        m(pixel_values=torch.zeros(1, 3, 224, 224))
+
+
+def test_swin_create_rejects_unbuilt_geometries(lib):
+    def create(**kw):
+        base = dict(image_size=224, patch_size=4, num_channels=3, embed_dim=96, num_stages=4, window_size=7, num_labels=5,
+                    mlp_ratio=4.0, ln_eps=1e-5, precision=0, reserved=0)
+        base.update(kw)
+        heads = base.pop("heads", (3, 6, 12, 24))
+        cfg = _lib.OcmSwinConfig(**base)
+        for i in range(4):
+            cfg.depths[i], cfg.num_heads[i] = (2, 2, 6, 2)[i], heads[i]
+        h = C.c_void_p(0)
+        return lib.ocm_swin_create(C.byref(cfg), C.byref(h))
+
+    for bad in (dict(patch_size=8), dict(window_size=8), dict(image_size=200), dict(heads=(4, 6, 12, 24)), dict(embed_dim=100),
+                dict(num_labels=0), dict(precision=3)):
+        assert create(**bad) == _lib.OCM_EINVAL, bad
+
+
+# ------------------------------------------------------------------------------------------------
+def _window_attention_oracle(qkv, B, H, W, heads, ws, shift, table):
+    """(shifted-)window attention of SwinLayer.forward on already projected q|k|v tokens."""
+    C_ = heads * 32
+    t = qkv.view(B, H, W, 3 * C_)
+    if shift:
+        t = torch.roll(t, shifts=(-shift, -shift), dims=(1, 2))
+    win = SO.window_partition(t, ws).view(-1, ws * ws, 3, heads, 32)
+    q, k, v = (win[:, :, i].transpose(1, 2) for i in range(3))
+    bias = table[SO.relative_position_index(ws).view(-1)].view(ws * ws, ws * ws, -1).permute(2, 0, 1).unsqueeze(0)
+    s = q @ k.transpose(2, 3) * 32 ** -0.5 + bias
+    m = SO.shift_mask(H, W, ws, shift)
+    if m is not None:
+        nW = m.shape[0]
+        s = s + m.unsqueeze(1).unsqueeze(0).expand(win.shape[0] // nW, -1, -1, -1, -1).reshape(-1, 1, ws * ws, ws * ws)
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(-1, ws, ws, C_)
+    o = SO.window_reverse(o, ws, H, W)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return o.reshape(B * H * W, C_)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("H,W,ws,shift,heads", [(14, 14, 7, 0, 3), (14, 14, 7, 3, 3), (28, 14, 7, 3, 6), (7, 7, 7, 0, 12),
+                                              (8, 12, 4, 2, 2)])
+def test_window_attention_op(lib, dev, precision, tol, H, W, ws, shift, heads):
+    B, C_ = 2, heads * 32
+    g = torch.Generator().manual_seed(H * 100 + W + shift)
+    qkv = torch.randn(B * H * W, 3 * C_, generator=g)
+    qkv[:, :2 * C_] *= 1.5
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g)
+    e = torch.float32 if precision == "fp32" else torch.bfloat16
+    qd = qkv.to(e).to(dev)
+    want = _window_attention_oracle(qd.float().cpu(), B, H, W, heads, ws, shift, table)
+    ctx = torch.full((B * H * W, C_), float("nan"), dtype=e, device=dev)
+    scratch = torch.empty(heads * (4096 + ws ** 4), dtype=torch.float32, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ocm_op_swin_window_attention(_lib.PRECISIONS[precision], C.c_void_p(qd.data_ptr()), 3 * C_,
+                                                C.c_void_p(ctx.data_ptr()), C_, C.c_void_p(table.to(dev).data_ptr()),
+                                                C.c_void_p(scratch.data_ptr()), B, H, W, ws, shift, heads, st))
+    got = ctx.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - want).abs().max().item() <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("name", sorted(SWIN_CASES))
+def test_swin_matches_transformers_fixture(dev, name, precision, tol):
+    """SwinForImageClassification on the HIP path against the outputs of the installed transformers model
+    (fixtures). fp32 mode: round-off of 12-24 layers; bf16 mode: logits are O(1), tolerance 6e-2 abs."""
+    c, cfg, sd, x = _case(name)
+    g = load_golden("swin_" + name)
+    hf = SW.SwinConfig(image_size=cfg["image_size"], depths=cfg["depths"], num_heads=cfg["num_heads"], num_labels=cfg["num_labels"])
+    model = SW.SwinForImageClassification(hf)
+    assert not model.load_state_dict(sd, strict=True).missing_keys
+    model = model.to(dev).eval().set_precision(precision)
+    out = model(pixel_values=x.to(dev), output_hidden_states=True)
+    assert np.abs(out.logits.cpu().numpy() - g["logits"]).max() <= tol
+    assert np.abs(out.pooler_output.cpu().numpy() - g["pooled"]).max() <= tol
+    assert np.abs(out.last_hidden_state[:, :8, :64].cpu().numpy() - g["last_hidden_head"]).max() <= 4 * tol
+    assert np.array_equal(out.logits.argmax(-1).cpu().numpy(), g["logits"].argmax(-1))

@@ -78,7 +78,25 @@ class OcmVitIO(C.Structure):
     ]
 
 
-# name -> (restype, argtypes); every symbol include/ocm_vit.h declares
+class OcmSwinConfig(C.Structure):  # include/ocm_swin.h
+    _fields_ = [
+        ("image_size", C.c_int32),
+        ("patch_size", C.c_int32),
+        ("num_channels", C.c_int32),
+        ("embed_dim", C.c_int32),
+        ("num_stages", C.c_int32),
+        ("depths", C.c_int32 * 4),
+        ("num_heads", C.c_int32 * 4),
+        ("window_size", C.c_int32),
+        ("num_labels", C.c_int32),
+        ("mlp_ratio", C.c_float),
+        ("ln_eps", C.c_float),
+        ("precision", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/ocm_vit.h and include/ocm_swin.h declare
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "ocm_abi_version": (C.c_int, []),
@@ -107,6 +125,16 @@ SIGNATURES = {
     "ocm_op_normalize_u8": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ocm_otsu_threshold": (_i32, [C.POINTER(C.c_uint64), _i64]),
     "ocm_op_threshold_u8": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "ocm_swin_create": (C.c_int, [C.POINTER(OcmSwinConfig), C.POINTER(C.c_void_p)]),
+    "ocm_swin_destroy": (None, [C.c_void_p]),
+    "ocm_swin_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "ocm_swin_params_ready": (C.c_int, [C.c_void_p]),
+    "ocm_swin_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
+    "ocm_swin_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_size_t, C.c_void_p]),
+    "ocm_op_swin_window_attention": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                               C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                               C.c_int32, C.c_void_p]),
     "ocm_op_pixel_shuffle": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_head_mean": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_image_to_gray_u8": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),

@@ -69,6 +69,16 @@ __device__ __forceinline__ void xcd_remap2(int &bx, int &by) {
     bx = id - by * (int)gridDim.x;
 }
 
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// key held by accumulator register `reg` of lane half `h` when K rows are loaded in pi order
+__device__ __forceinline__ int key_of_reg(int reg, int h) {
+    return (reg & 3) + 4 * ((reg >> 2) & 1) + 8 * h + 16 * (reg >> 3);
+}
+__device__ __forceinline__ int pi_row(int r) {  // swap bits 2 and 3
+    return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+}
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. fp32-grade) on the hardware
 // reciprocal / exp2 units: ~12 VALU ops instead of libm erff's ~50, which made the fc1 epilogue
 // cost more than its MFMA main loop.

@@ -8,12 +8,12 @@
 #include <string>
 #include <vector>
 
-#include "../../include/ocm_vit.h"
+#include "host_common.h"
 #include "launch.h"
 
 static thread_local std::string g_err;
 
-static int fail(int code, const char *fmt, ...) {
+int ocm_fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -22,12 +22,7 @@ static int fail(int code, const char *fmt, ...) {
     g_err = buf;
     return code;
 }
-#define HIP_TRY(expr)                                                                             \
-    do {                                                                                          \
-        hipError_t e_ = (expr);                                                                   \
-        if (e_ != hipSuccess) return fail(OCM_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), \
-                                          __FILE__, __LINE__);                                    \
-    } while (0)
+#define fail ocm_fail
 
 // ------------------------------------------------------------------------------------------
 // kernel-class timing with hipEvents (diagnostic)

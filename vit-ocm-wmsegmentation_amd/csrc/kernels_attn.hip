@@ -30,16 +30,6 @@
 
 #define LOG2E 1.4426950408889634f
 
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-// key held by accumulator register `reg` of lane half `h` when K rows are loaded in pi order
-__device__ __forceinline__ int key_of_reg(int reg, int h) {
-    return (reg & 3) + 4 * ((reg >> 2) & 1) + 8 * h + 16 * (reg >> 3);
-}
-__device__ __forceinline__ int pi_row(int r) {  // swap bits 2 and 3
-    return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
-}
-
 template <bool WANT_O>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ Q, const bf16 *__restrict__ Kk,
                                                        const bf16 *__restrict__ Vt, bf16 *__restrict__ ctx,

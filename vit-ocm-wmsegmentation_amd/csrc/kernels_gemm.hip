@@ -146,6 +146,38 @@ static hipError_t launch_linear_e(const E *a, const E *w, const float *bias, con
     return hipErrorInvalidValue;
 }
 
+// nn.Linear with explicit row strides (Swin: activations padded to the GEMM's K step, N not a multiple of the
+// tile). N tails are handled by the loaders' row clamps and the epilogue's column guards.
+template <int MODE, class E>
+static hipError_t launch_linear_ld_mode(const E *a, int64_t lda, const E *w, const float *bias, const float *resid,
+                                        void *out, int64_t ldo, int M, int N, int K, hipStream_t s) {
+    RowLoader<E> al{a, lda};
+    EpiLinear<MODE, E> epi{bias, resid, out, M, N, ldo};
+    if (M >= 2048 && N > 64) return launch_gemm<Cfg128x128, E, false>(al, w, K, M, N, K, epi, s);
+    if (M > 64 && N > 64) return launch_gemm<Cfg64x128, E, false>(al, w, K, M, N, K, epi, s);
+    return launch_gemm<Cfg64x64, E, false>(al, w, K, M, N, K, epi, s);
+}
+
+template <class E>
+static hipError_t launch_linear_ld_e(const E *a, int64_t lda, const E *w, const float *bias, const float *resid, void *out,
+                                     int64_t ldo, int M, int N, int K, int epilogue, hipStream_t s) {
+    switch (epilogue) {
+        case 0: return launch_linear_ld_mode<0, E>(a, lda, w, bias, resid, out, ldo, M, N, K, s);
+        case 1: return launch_linear_ld_mode<1, E>(a, lda, w, bias, resid, out, ldo, M, N, K, s);
+        case 2: return launch_linear_ld_mode<2, E>(a, lda, w, bias, resid, out, ldo, M, N, K, s);
+        case 3: return launch_linear_ld_mode<3, E>(a, lda, w, bias, resid, out, ldo, M, N, K, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_linear_ld(int prec, const void *a, int64_t lda, const void *w, const float *bias, const float *resid,
+                            void *out, int64_t ldo, int M, int N, int K, int epilogue, hipStream_t s) {
+    if (prec)
+        return launch_linear_ld_e<float>((const float *)a, lda, (const float *)w, bias, resid, out, ldo, M, N, K, epilogue,
+                                         s);
+    return launch_linear_ld_e<bf16>((const bf16 *)a, lda, (const bf16 *)w, bias, resid, out, ldo, M, N, K, epilogue, s);
+}
+
 hipError_t launch_linear(int prec, const void *a, const void *w, const float *bias, const float *resid, void *out, int M,
                          int N, int K, int epilogue, hipStream_t s) {
     if (prec) return launch_linear_e<float>((const float *)a, (const float *)w, bias, resid, out, M, N, K, epilogue, s);

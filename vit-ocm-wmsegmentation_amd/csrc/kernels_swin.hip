@@ -1,0 +1,522 @@
+// kernels_swin.hip — the Swin-specific stages of the Swin-T forward (BASELINE config 5;
+// arithmetic = transformers/models/swin/modeling_swin.py, the reference's dependency at
+// Allen_data_Backbone/train.py:70-85). The projections and the MLP reuse the MFMA GEMMs of kernels_gemm.hip;
+// here are the pieces with Swin's own data movement:
+//   swin_embed_kernel      4x4 stride-4 conv + bias + LayerNorm            (SwinEmbeddings.forward :219-244)
+//   swin_ln_kernel         LayerNorm with an output row stride (K padded to the GEMM step) and, for patch
+//                          merging, the 2x2 neighbour gather fused in front   (SwinPatchMerging.forward :309-326)
+//   swin_bias_perm_kernel  relative-position bias table -> dense bias in the attention kernel's register order
+//   swin_wattn_kernel      (shifted-)window attention: cyclic shift, window partition, q k^T * scale + bias + mask,
+//                          softmax, P v, window reverse, shift back — one wavefront per (window, head), K and V^T
+//                          of the window staged in LDS, both contractions on MFMA   (SwinLayer.forward :529-574)
+//   swin_wattn_f32_kernel  the same in plain fp32 FMAs (OCM_PREC_FP32)
+//   swin_pool_head_kernel  final LayerNorm + mean over tokens + classifier       (SwinModel :887-892, :1052)
+#include "launch.h"
+
+// ------------------------------------------------------------------------------------------
+// patch embedding: one wavefront per token, weights of the lane's output channels in registers, the 48 patch
+// values broadcast lane -> scalar with v_readlane
+// ------------------------------------------------------------------------------------------
+template <int U>  // output channels per lane: C0 <= 64 * U
+__global__ __launch_bounds__(256) void swin_embed_kernel(const float *__restrict__ img, const float *__restrict__ w,
+                                                         const float *__restrict__ bias, const float *__restrict__ g,
+                                                         const float *__restrict__ be, float *__restrict__ x, int B,
+                                                         int chans, int S, int C0, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int gw = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
+    const int hp = S / 4, K = chans * 16;  // K <= 64
+    float wr[U][48], br[U], gr[U], ber[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int c = min(lane + 64 * u, C0 - 1);
+        br[u] = bias[c];
+        gr[u] = g[c];
+        ber[u] = be[c];
+#pragma unroll
+        for (int k = 0; k < 48; ++k) wr[u][k] = k < K ? w[c * K + k] : 0.f;
+    }
+    const int ch = lane >> 4, dy = (lane >> 2) & 3, dx = lane & 3;  // lane -> (channel, dy, dx) of the patch
+    const size_t T = (size_t)B * hp * hp;
+    for (size_t t = gw; t < T; t += nw) {
+        const int b = (int)(t / (hp * hp)), pi = (int)(t - (size_t)b * hp * hp);
+        const int py = pi / hp, px = pi - py * hp;
+        float v = 0.f;
+        if (lane < K) v = img[(((size_t)b * chans + ch) * S + py * 4 + dy) * S + px * 4 + dx];
+        float acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = br[u];
+#pragma unroll
+        for (int k = 0; k < 48; ++k) {
+            const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc[u] = fmaf(s, wr[u][k], acc[u]);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) sum += (lane + 64 * u < C0) ? acc[u] : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum / (float)C0;
+        float var = 0.f;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float d = acc[u] - mean;
+            var += (lane + 64 * u < C0) ? d * d : 0.f;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+        const float rstd = rsqrtf(var / (float)C0 + eps);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (lane + 64 * u < C0) x[t * C0 + lane + 64 * u] = (acc[u] - mean) * rstd * gr[u] + ber[u];
+    }
+}
+
+hipError_t launch_swin_embed(const float *img, const float *w, const float *bias, const float *g, const float *be,
+                             float *x, int batch, int chans, int size, int c0, float eps, hipStream_t s) {
+    const size_t T = (size_t)batch * (size / 4) * (size / 4);
+    const unsigned blocks = (unsigned)((T + 31) / 32 < 2048 ? (T + 31) / 32 : 2048);
+    if (c0 <= 64)
+        swin_embed_kernel<1><<<dim3(blocks), dim3(256), 0, s>>>(img, w, bias, g, be, x, batch, chans, size, c0, eps);
+    else if (c0 <= 128)
+        swin_embed_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(img, w, bias, g, be, x, batch, chans, size, c0, eps);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm -> GEMM operand rows of stride ldy (columns [dim, ldy) zero). MERGE: row = merged token,
+// its 4*C inputs are the four 2x2 neighbours in the order (row0,col0), (row1,col0), (row0,col1), (row1,col1).
+// ------------------------------------------------------------------------------------------
+template <class E, bool MERGE, int V>  // V = ceil(dim / 64)
+__global__ __launch_bounds__(256) void swin_ln_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                      const float *__restrict__ be, E *__restrict__ y, size_t rows,
+                                                      int dim, int ldy, float eps, int Hin, int Win) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *src[4];
+    int C = dim;
+    if (MERGE) {
+        C = dim >> 2;
+        const int Ho = Hin >> 1, Wo = Win >> 1;
+        const size_t b = row / ((size_t)Ho * Wo);
+        const int rem = (int)(row - b * Ho * Wo), yo = rem / Wo, xo = rem - yo * Wo;
+#pragma unroll
+        for (int sgm = 0; sgm < 4; ++sgm) {
+            const int r = sgm & 1, c = sgm >> 1;
+            src[sgm] = x + ((b * Hin + 2 * yo + r) * Win + 2 * xo + c) * (size_t)C;
+        }
+    } else {
+        src[0] = x + row * (size_t)dim;
+    }
+    float v[V];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = lane + 64 * i;
+        float t = 0.f;
+        if (c < dim) t = MERGE ? src[c / C][c % C] : src[0][c];
+        v[i] = t;
+        sum += t;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float mean = sum / (float)dim;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const float d = v[i] - mean;
+        var += (lane + 64 * i < dim) ? d * d : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    const float rstd = rsqrtf(var / (float)dim + eps);
+    E *dst = y + row * (size_t)ldy;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const int c = lane + 64 * i;
+        if (c < dim)
+            dst[c] = (E)((v[i] - mean) * rstd * g[c] + be[c]);
+        else if (c < ldy)
+            dst[c] = (E)0.f;
+    }
+    if (64 * V < ldy)
+        for (int c = 64 * V + lane; c < ldy; c += 64) dst[c] = (E)0.f;
+}
+
+template <class E, bool MERGE>
+static hipError_t launch_swin_ln_e(const float *x, const float *g, const float *be, E *y, size_t rows, int dim, int ldy,
+                                   float eps, int Hin, int Win, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    const int V = (dim + 63) / 64;
+#define OCM_LN_CASE(v)                                                                                       \
+    if (V <= v) {                                                                                            \
+        swin_ln_kernel<E, MERGE, v><<<grid, block, 0, s>>>(x, g, be, y, rows, dim, ldy, eps, Hin, Win);      \
+        return hipGetLastError();                                                                            \
+    }
+    OCM_LN_CASE(2) OCM_LN_CASE(3) OCM_LN_CASE(6) OCM_LN_CASE(12) OCM_LN_CASE(24)
+#undef OCM_LN_CASE
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_swin_ln(int prec, const float *x, const float *g, const float *be, void *y, size_t rows, int dim,
+                          int ldy, float eps, bool merge, int Hin, int Win, hipStream_t s) {
+    if (rows == 0) return hipSuccess;
+    if (prec) {
+        return merge ? launch_swin_ln_e<float, true>(x, g, be, (float *)y, rows, dim, ldy, eps, Hin, Win, s)
+                     : launch_swin_ln_e<float, false>(x, g, be, (float *)y, rows, dim, ldy, eps, Hin, Win, s);
+    }
+    return merge ? launch_swin_ln_e<bf16, true>(x, g, be, (bf16 *)y, rows, dim, ldy, eps, Hin, Win, s)
+                 : launch_swin_ln_e<bf16, false>(x, g, be, (bf16 *)y, rows, dim, ldy, eps, Hin, Win, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// relative-position bias (SwinRelativePositionBias :329-370) in the attention kernels' order, times log2(e):
+//   out[head][qt][lane][sub*16 + e] = table[index(i, j)][head] * log2e,  i = qt*32 + (lane & 31),
+//   j = sub*32 + key_of_reg(e, lane >> 5); keys j >= ws*ws get -1e30 (the padding mask), queries i >= ws*ws 0.
+// `dense` (optional) receives the plain [head][ws*ws][ws*ws] table (natural-log domain) for the fp32 kernel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swin_bias_perm_kernel(const float *__restrict__ table, float *__restrict__ perm,
+                                                             float *__restrict__ dense, int heads, int ws) {
+    const int A = ws * ws;
+    const int total = heads * 2 * 64 * 32;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int e32 = idx & 31, lane = (idx >> 5) & 63, qt = (idx >> 11) & 1, head = idx >> 12;
+        const int sub = e32 >> 4, e = e32 & 15;
+        const int i = qt * 32 + (lane & 31), j = sub * 32 + key_of_reg(e, lane >> 5);
+        float v = 0.f;
+        if (j >= A) {
+            v = -1e30f;
+        } else if (i < A) {
+            const int yi = i / ws, xi = i - yi * ws, yj = j / ws, xj = j - yj * ws;
+            v = table[((yi - yj + ws - 1) * (2 * ws - 1) + (xi - xj + ws - 1)) * heads + head] * 1.4426950408889634f;
+        }
+        perm[idx] = v;
+    }
+    if (dense) {
+        const int tot2 = heads * A * A;
+        for (int idx = blockIdx.x * 256 + threadIdx.x; idx < tot2; idx += gridDim.x * 256) {
+            const int j = idx % A, i = (idx / A) % A, head = idx / (A * A);
+            const int yi = i / ws, xi = i - yi * ws, yj = j / ws, xj = j - yj * ws;
+            dense[idx] = table[((yi - yj + ws - 1) * (2 * ws - 1) + (xi - xj + ws - 1)) * heads + head];
+        }
+    }
+}
+
+hipError_t launch_swin_bias_perm(const float *table, float *perm, float *dense, int heads, int ws, hipStream_t s) {
+    swin_bias_perm_kernel<<<dim3(64), dim3(256), 0, s>>>(table, perm, dense, heads, ws);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// window attention
+// ------------------------------------------------------------------------------------------
+struct WinGeom {
+    int H, W, ws, shift, nWx, nW, heads;
+};
+// token (row of the (B, H*W, C) stream) of position p of window (b, wy, wx): the window tiles the image rolled
+// by -shift (cyclic_shift :617-626 + window_partition :486-495), so its source pixel is (+shift) mod size; the
+// output goes back to the same token (window_reverse + reverse roll).
+__device__ __forceinline__ size_t win_token(const WinGeom &g, int b, int wy, int wx, int p) {
+    const int py = p / g.ws, px = p - py * g.ws;
+    int y = wy * g.ws + py + g.shift, x = wx * g.ws + px + g.shift;
+    if (y >= g.H) y -= g.H;
+    if (x >= g.W) x -= g.W;
+    return ((size_t)b * g.H + y) * g.W + x;
+}
+// region id of get_attn_mask (:584-607) for position p of the window, in the SHIFTED frame
+__device__ __forceinline__ int win_region(const WinGeom &g, int wy, int wx, int p) {
+    const int py = p / g.ws, px = p - py * g.ws;
+    const int ys = wy * g.ws + py, xs = wx * g.ws + px;
+    const int ry = (ys >= g.H - g.ws) + (ys >= g.H - g.shift), rx = (xs >= g.W - g.ws) + (xs >= g.W - g.shift);
+    return ry * 3 + rx;
+}
+
+// bf16 / MFMA: one wavefront per (b, window, head), head_dim 32, ws*ws <= 64 positions.
+// S^T = K.Q^T with the K rows in pi order (common.h): registers hold keys, the lane holds the query, so the
+// row max / sum are in-register reductions plus one lane <-> lane+32 exchange and the exponentiated tile is
+// directly the B operand of O^T += V^T.P^T (same scheme as kernels_attn.hip).
+__global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict__ qkv, int ld, bf16 *__restrict__ ctx,
+                                                         int ldc, const float *__restrict__ bias_perm, WinGeom g,
+                                                         int total, float scale2) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * (64 * 64 + 32 * 128 + 64)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int id = blockIdx.x * 4 + wave;
+    if (id >= total) return;  // no workgroup barrier below: every wave owns its LDS slice
+    char *Ks = smem + wave * (64 * 64 + 32 * 128 + 64);  // K: 64 keys x 64 B
+    char *Vs = Ks + 64 * 64;                             // V^T: 32 dims x 128 B (lds_off swizzle)
+    unsigned char *Rg = (unsigned char *)(Vs + 32 * 128);
+    const int head = id % g.heads, wlin = (id / g.heads) % g.nW, b = id / (g.heads * g.nW);
+    const int wy = wlin / g.nWx, wx = wlin - wy * g.nWx;
+    const int A = g.ws * g.ws, C = g.heads * 32;
+    const bf16 *base = qkv + head * 32;
+
+    // stage K rows and V^T columns of the window (padding keys: exact zeros)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i, key = idx >> 2, ch = idx & 3;
+        bf16x8 kv, vv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kv[e] = vv[e] = (bf16)0.f;
+        if (key < A) {
+            const bf16 *row = base + win_token(g, b, wy, wx, key) * (size_t)ld + ch * 8;
+            kv = *(const bf16x8 *)(row + C);
+            vv = *(const bf16x8 *)(row + 2 * C);
+        }
+        *(bf16x8 *)(Ks + key * 64 + ch * 16) = kv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = ch * 8 + e;
+            *(bf16 *)(Vs + lds_off(d, key >> 3) + (key & 7) * 2) = vv[e];
+        }
+    }
+    const bool masked = g.shift > 0 && (wy == g.H / g.ws - 1 || wx == g.nWx - 1);  // wave-uniform
+    if (masked) Rg[lane] = (unsigned char)(lane < A ? win_region(g, wy, wx, lane) : 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+
+    const int pr = pi_row(r);
+    const float *bp = bias_perm + (size_t)head * 2 * 64 * 32 + lane * 32;
+#pragma unroll 1
+    for (int qt = 0; qt < 2; ++qt) {
+        if (qt * 32 >= A) break;
+        const int qi = qt * 32 + r;
+        const size_t qtok = win_token(g, b, wy, wx, min(qi, A - 1));
+        bf16x8 qf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[s] = *(const bf16x8 *)(base + qtok * (size_t)ld + 16 * s + 8 * h);
+        f32x16 S[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[sub][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 a = *(const bf16x8 *)(Ks + (sub * 32 + pr) * 64 + (2 * s + h) * 16);
+                S[sub] = mfma32(a, qf[s], S[sub]);
+            }
+        }
+        const float *bq = bp + qt * 64 * 32;
+        float mx = -INFINITY;
+        const int myreg = masked ? Rg[min(qi, A - 1)] : 0;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const f32x4 bv = *(const f32x4 *)(bq + sub * 16 + e4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(S[sub][e4 * 4 + e], scale2, bv[e]);
+                    if (masked) {
+                        const int j = sub * 32 + key_of_reg(e4 * 4 + e, h);
+                        if (j < A && Rg[j] != myreg) v += -100.0f * 1.4426950408889634f;
+                    }
+                    S[sub][e4 * 4 + e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = fast_exp2(S[sub][e] - mx);
+                S[sub][e] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 32, 64);
+        f32x16 O;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[e] = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pb;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[e] = (bf16)S[sub][8 * s2 + e];
+                const bf16x8 a = *(const bf16x8 *)(Vs + lds_off(r, 4 * sub + 2 * s2 + h));
+                O = mfma32(a, pb, O);
+            }
+        if (qi < A) {
+            const float inv = 1.0f / l;
+            bf16 *dst = ctx + qtok * (size_t)ldc + head * 32;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(O[4 * gq + e] * inv);
+                *(bf16x4 *)(dst + 8 * gq + 4 * h) = o;
+            }
+        }
+    }
+}
+
+// fp32 (OCM_PREC_FP32): one wavefront per (b, window, head); lane = query, K / V rows broadcast from LDS.
+__global__ __launch_bounds__(256) void swin_wattn_f32_kernel(const float *__restrict__ qkv, int ld,
+                                                             float *__restrict__ ctx, int ldc,
+                                                             const float *__restrict__ bias_dense, WinGeom g, int total,
+                                                             float scale) {
+    __shared__ float smem[4 * (2 * 49 * 32)];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int id = blockIdx.x * 4 + wave;
+    if (id >= total) return;
+    float *Ks = smem + wave * (2 * 49 * 32), *Vs = Ks + 49 * 32;
+    const int head = id % g.heads, wlin = (id / g.heads) % g.nW, b = id / (g.heads * g.nW);
+    const int wy = wlin / g.nWx, wx = wlin - wy * g.nWx;
+    const int A = g.ws * g.ws, C = g.heads * 32;
+    const float *base = qkv + head * 32;
+    for (int idx = lane; idx < A * 8; idx += 64) {
+        const int key = idx >> 3, ch = idx & 7;
+        const float *row = base + win_token(g, b, wy, wx, key) * (size_t)ld + ch * 4;
+        *(f32x4 *)(Ks + key * 32 + ch * 4) = *(const f32x4 *)(row + C);
+        *(f32x4 *)(Vs + key * 32 + ch * 4) = *(const f32x4 *)(row + 2 * C);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+    if (lane >= A) return;
+    const size_t qtok = win_token(g, b, wy, wx, lane);
+    float q[32];
+#pragma unroll
+    for (int d = 0; d < 32; d += 4) {
+        const f32x4 t = *(const f32x4 *)(base + qtok * (size_t)ld + d);
+        q[d] = t[0]; q[d + 1] = t[1]; q[d + 2] = t[2]; q[d + 3] = t[3];
+    }
+    const bool masked = g.shift > 0;
+    const int myreg = masked ? win_region(g, wy, wx, lane) : 0;
+    const float *brow = bias_dense + ((size_t)head * A + lane) * A;
+    float sc[49];
+    float mx = -INFINITY;
+#pragma unroll 7
+    for (int j = 0; j < 49; ++j) {
+        float s = -INFINITY;
+        if (j < A) {
+            float d0 = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) d0 = fmaf(q[d], Ks[j * 32 + d], d0);
+            s = d0 * scale + brow[j];
+            if (masked && win_region(g, wy, wx, j) != myreg) s += -100.0f;
+        }
+        sc[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    float o[32], l = 0.f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+#pragma unroll 7
+    for (int j = 0; j < 49; ++j) {
+        if (j < A) {
+            const float p = __expf(sc[j] - mx);
+            l += p;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) o[d] = fmaf(p, Vs[j * 32 + d], o[d]);
+        }
+    }
+    const float inv = 1.0f / l;
+    float *dst = ctx + qtok * (size_t)ldc + head * 32;
+#pragma unroll
+    for (int d = 0; d < 32; d += 4) *(f32x4 *)(dst + d) = f32x4{o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv};
+}
+
+hipError_t launch_swin_window_attention(int prec, const void *qkv, int ld, void *ctx, int ldc, const float *bias_perm,
+                                        const float *bias_dense, int batch, int H, int W, int ws, int shift, int heads,
+                                        hipStream_t s) {
+    if (ws * ws > 49 + 15 || H % ws || W % ws) return hipErrorInvalidValue;
+    WinGeom g{H, W, ws, shift, W / ws, (H / ws) * (W / ws), heads};
+    const long total = (long)batch * g.nW * heads;
+    if (total <= 0 || total > 0x7fffffffL) return hipErrorInvalidValue;
+    const unsigned blocks = (unsigned)((total + 3) / 4);
+    const float scale = 0.17677669529663687f;  // 32^-0.5 (SwinAttention.scaling :408)
+    if (prec)
+        swin_wattn_f32_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const float *)qkv, ld, (float *)ctx, ldc, bias_dense, g,
+                                                                  (int)total, scale);
+    else
+        swin_wattn_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const bf16 *)qkv, ld, (bf16 *)ctx, ldc, bias_perm, g,
+                                                              (int)total, scale * 1.4426950408889634f);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// final LayerNorm + AdaptiveAvgPool1d(1) + classifier: one workgroup per image
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swin_pool_head_kernel(const float *__restrict__ x, const float *__restrict__ g,
+                                                             const float *__restrict__ be, const float *__restrict__ cw,
+                                                             const float *__restrict__ cb, float *__restrict__ logits,
+                                                             float *__restrict__ pooled, float *__restrict__ hidden,
+                                                             int L, int C, int labels, float eps) {
+    extern __shared__ float sm[];  // [4 waves][C] partial pooled sums, then [C] pooled
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *part = sm + wave * C;
+    for (int c = lane; c < C; c += 64) part[c] = 0.f;
+    for (int t = wave; t < L; t += 4) {
+        const float *row = x + ((size_t)b * L + t) * C;
+        float sum = 0.f;
+        for (int c = lane; c < C; c += 64) sum += row[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        const float mean = sum / (float)C;
+        float var = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float d = row[c] - mean;
+            var += d * d;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+        const float rstd = rsqrtf(var / (float)C + eps);
+        for (int c = lane; c < C; c += 64) {
+            const float v = (row[c] - mean) * rstd * g[c] + be[c];
+            if (hidden) hidden[((size_t)b * L + t) * C + c] = v;
+            part[c] += v;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float v = (sm[c] + sm[C + c] + sm[2 * C + c] + sm[3 * C + c]) / (float)L;
+        sm[4 * C + c] = v;
+        if (pooled) pooled[(size_t)b * C + c] = v;
+    }
+    __syncthreads();
+    const float *pv = sm + 4 * C;
+    for (int o = wave; o < labels; o += 4) {
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc = fmaf(pv[c], cw[(size_t)o * C + c], acc);
+#pragma unroll
+        for (int k = 32; k > 0; k >>= 1) acc += __shfl_xor(acc, k, 64);
+        if (lane == 0) logits[(size_t)b * labels + o] = acc + cb[o];
+    }
+}
+
+hipError_t launch_swin_pool_head(const float *x, const float *g, const float *be, const float *cw, const float *cb,
+                                 float *logits, float *pooled, float *hidden, int batch, int L, int C, int labels,
+                                 float eps, hipStream_t s) {
+    swin_pool_head_kernel<<<dim3(batch), dim3(256), 5 * C * sizeof(float), s>>>(x, g, be, cw, cb, logits, pooled, hidden,
+                                                                                 L, C, labels, eps);
+    return hipGetLastError();
+}
+
+// fp32 [rows][K] -> E [rows][Kp] with zero padding (weight upload; K padded to the GEMM's LDS row)
+template <class E>
+__global__ __launch_bounds__(256) void cast_pad_kernel(const float *__restrict__ src, E *__restrict__ dst, size_t rows,
+                                                       int K, int Kp) {
+    const size_t total = rows * Kp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / Kp;
+        const int c = (int)(i - r * Kp);
+        dst[i] = (E)(c < K ? src[r * K + c] : 0.f);
+    }
+}
+
+hipError_t launch_cast_pad(int prec, const float *src, void *dst, size_t rows, int K, int Kp, hipStream_t s) {
+    const size_t total = rows * Kp;
+    unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (blocks == 0) return hipSuccess;
+    if (prec)
+        cast_pad_kernel<float><<<dim3(blocks), dim3(256), 0, s>>>(src, (float *)dst, rows, K, Kp);
+    else
+        cast_pad_kernel<bf16><<<dim3(blocks), dim3(256), 0, s>>>(src, (bf16 *)dst, rows, K, Kp);
+    return hipGetLastError();
+}

@@ -59,3 +59,19 @@ hipError_t launch_blend_u8(const uint8_t *img, const uint8_t *att, size_t count,
                            uint8_t *out, unsigned long long *hist256, hipStream_t s);
 
 static inline int ocm_round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---- Swin (kernels_swin.hip, kernels_gemm.hip)
+hipError_t launch_linear_ld(int prec, const void *a, int64_t lda, const void *w, const float *bias, const float *resid,
+                            void *out, int64_t ldo, int M, int N, int K, int epilogue, hipStream_t s);
+hipError_t launch_swin_embed(const float *img, const float *w, const float *bias, const float *g, const float *be,
+                             float *x, int batch, int chans, int size, int c0, float eps, hipStream_t s);
+hipError_t launch_swin_ln(int prec, const float *x, const float *g, const float *be, void *y, size_t rows, int dim,
+                          int ldy, float eps, bool merge, int Hin, int Win, hipStream_t s);
+hipError_t launch_swin_bias_perm(const float *table, float *perm, float *dense, int heads, int ws, hipStream_t s);
+hipError_t launch_swin_window_attention(int prec, const void *qkv, int ld, void *ctx, int ldc, const float *bias_perm,
+                                        const float *bias_dense, int batch, int H, int W, int ws, int shift, int heads,
+                                        hipStream_t s);
+hipError_t launch_swin_pool_head(const float *x, const float *g, const float *be, const float *cw, const float *cb,
+                                 float *logits, float *pooled, float *hidden, int batch, int L, int C, int labels,
+                                 float eps, hipStream_t s);
+hipError_t launch_cast_pad(int prec, const float *src, void *dst, size_t rows, int K, int Kp, hipStream_t s);

@@ -123,3 +123,66 @@ def synth_patch_mask(batch, side, *, seed=7, ratio=0.6):
     """SimMIM-style 0/1 patch mask (B, side, side) int64 with about `ratio` of the patches masked."""
     v = _rng(seed, "patch_mask").uniform(0, 1, size=(batch, side, side))
     return torch.from_numpy((v < ratio).astype(np.int64))
+
+
+# ---- Swin-T (SURVEY §8-f row 4): HF `SwinForImageClassification` state_dict keys and shapes ----
+SWIN_TINY = dict(image_size=224, patch_size=4, num_channels=3, embed_dim=96, depths=(2, 2, 6, 2),
+                 num_heads=(3, 6, 12, 24), window_size=7, mlp_ratio=4.0, layer_norm_eps=1e-5, num_labels=5)
+
+
+def swin_param_shapes(cfg):
+    C0, p, ws = cfg["embed_dim"], cfg["patch_size"], cfg["window_size"]
+    shapes = {
+        "swin.embeddings.patch_embeddings.projection.weight": (C0, cfg["num_channels"], p, p),
+        "swin.embeddings.patch_embeddings.projection.bias": (C0,),
+        "swin.embeddings.norm.weight": (C0,), "swin.embeddings.norm.bias": (C0,),
+    }
+    ns = len(cfg["depths"])
+    for s, (depth, heads) in enumerate(zip(cfg["depths"], cfg["num_heads"])):
+        C = C0 * 2 ** s
+        M = int(cfg["mlp_ratio"] * C)
+        for b in range(depth):
+            pre = f"swin.encoder.layers.{s}.blocks.{b}."
+            for nm in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                shapes[pre + f"attention.{nm}.weight"] = (C, C)
+                shapes[pre + f"attention.{nm}.bias"] = (C,)
+            shapes[pre + "attention.relative_position_bias.relative_position_bias_table"] = ((2 * ws - 1) ** 2, heads)
+            for nm in ("layernorm_before", "layernorm_after"):
+                shapes[pre + nm + ".weight"] = (C,)
+                shapes[pre + nm + ".bias"] = (C,)
+            shapes[pre + "mlp.fc1.weight"] = (M, C)
+            shapes[pre + "mlp.fc1.bias"] = (M,)
+            shapes[pre + "mlp.fc2.weight"] = (C, M)
+            shapes[pre + "mlp.fc2.bias"] = (C,)
+        if s < ns - 1:
+            pre = f"swin.encoder.layers.{s}.downsample."
+            shapes[pre + "reduction.weight"] = (2 * C, 4 * C)
+            shapes[pre + "norm.weight"] = (4 * C,)
+            shapes[pre + "norm.bias"] = (4 * C,)
+    Cl = C0 * 2 ** (ns - 1)
+    shapes.update({"swin.layernorm.weight": (Cl,), "swin.layernorm.bias": (Cl,),
+                   "classifier.weight": (cfg["num_labels"], Cl), "classifier.bias": (cfg["num_labels"],)})
+    return shapes
+
+
+def synth_swin_state_dict(cfg, *, seed=0, qk_gain=1.0):
+    """Deterministic Swin weights: Linear / table ~ N(0, 0.02^2) (HF _init_weights), random biases N(0, 0.02^2),
+    LayerNorm weight 1 + N(0, 0.1^2), bias N(0, 0.05^2), conv U(+-1/sqrt(fan_in)). `qk_gain` scales the q/k
+    projections and the relative-position table (peaked window attention for the parity tests)."""
+    sd = {}
+    for name, shape in swin_param_shapes(cfg).items():
+        if "projection" in name:
+            fan_in = cfg["num_channels"] * cfg["patch_size"] ** 2
+            t = _uniform(seed, name, shape, 1.0 / np.sqrt(fan_in))
+        elif "norm" in name:
+            t = 1.0 + _normal(seed, name, shape, 0.1) if name.endswith("weight") else _normal(seed, name, shape, 0.05)
+        elif name.endswith(".bias"):
+            t = _normal(seed, name, shape, 0.02)
+        else:
+            t = _normal(seed, name, shape, 0.02)
+            if "q_proj.weight" in name or "k_proj.weight" in name:
+                t = t * qk_gain
+            if "relative_position_bias_table" in name:
+                t = t * (25.0 * qk_gain)
+        sd[name] = t
+    return sd
