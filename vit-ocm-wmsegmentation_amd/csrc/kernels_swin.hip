@@ -37,11 +37,17 @@ __global__ __launch_bounds__(256) void swin_embed_kernel(const float *__restrict
     }
     const int ch = lane >> 4, dy = (lane >> 2) & 3, dx = lane & 3;  // lane -> (channel, dy, dx) of the patch
     const size_t T = (size_t)B * hp * hp;
-    for (size_t t = gw; t < T; t += nw) {
+    auto pixel = [&](size_t t) {  // this lane's input value of token t (clamped: the stream is unconditional)
+        t = t < T ? t : T - 1;
         const int b = (int)(t / (hp * hp)), pi = (int)(t - (size_t)b * hp * hp);
         const int py = pi / hp, px = pi - py * hp;
-        float v = 0.f;
-        if (lane < K) v = img[(((size_t)b * chans + ch) * S + py * 4 + dy) * S + px * 4 + dx];
+        return lane < K ? img[(((size_t)b * chans + ch) * S + py * 4 + dy) * S + px * 4 + dx] : 0.f;
+    };
+    float vn = pixel(gw), vn2 = pixel(gw + nw);
+    for (size_t t = gw; t < T; t += nw) {
+        const float v = vn;
+        vn = vn2;
+        vn2 = pixel(t + 2 * (size_t)nw);  // two tokens ahead: the HBM round trip overlaps two iterations of FMAs
         float acc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) acc[u] = br[u];
@@ -89,74 +95,93 @@ hipError_t launch_swin_embed(const float *img, const float *w, const float *bias
 // LayerNorm -> GEMM operand rows of stride ldy (columns [dim, ldy) zero). MERGE: row = merged token,
 // its 4*C inputs are the four 2x2 neighbours in the order (row0,col0), (row1,col0), (row0,col1), (row1,col1).
 // ------------------------------------------------------------------------------------------
-template <class E, bool MERGE, int V>  // V = ceil(dim / 64)
+template <class E>
+__device__ __forceinline__ void store4(E *dst, const f32x4 &v);
+template <>
+__device__ __forceinline__ void store4<float>(float *dst, const f32x4 &v) { *(f32x4 *)dst = v; }
+template <>
+__device__ __forceinline__ void store4<bf16>(bf16 *dst, const f32x4 &v) {
+    bf16x4 o;
+    o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
+    *(bf16x4 *)dst = o;
+}
+
+// LPR lanes per row (32: two rows per wavefront for dim <= 128; 64 otherwise), V float4 chunks per lane.
+template <class E, bool MERGE, int LPR, int V>
 __global__ __launch_bounds__(256) void swin_ln_kernel(const float *__restrict__ x, const float *__restrict__ g,
                                                       const float *__restrict__ be, E *__restrict__ y, size_t rows,
                                                       int dim, int ldy, float eps, int Hin, int Win) {
-    const int lane = threadIdx.x & 63;
-    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    constexpr int RPW = 64 / LPR;  // rows per wavefront
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const size_t row = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < rows;
+    const size_t rr = live ? row : rows - 1;  // clamped: every lane takes part in the shuffles
     const float *src[4];
     int C = dim;
     if (MERGE) {
         C = dim >> 2;
         const int Ho = Hin >> 1, Wo = Win >> 1;
-        const size_t b = row / ((size_t)Ho * Wo);
-        const int rem = (int)(row - b * Ho * Wo), yo = rem / Wo, xo = rem - yo * Wo;
+        const size_t b = rr / ((size_t)Ho * Wo);
+        const int rem = (int)(rr - b * Ho * Wo), yo = rem / Wo, xo = rem - yo * Wo;
 #pragma unroll
         for (int sgm = 0; sgm < 4; ++sgm) {
             const int r = sgm & 1, c = sgm >> 1;
             src[sgm] = x + ((b * Hin + 2 * yo + r) * Win + 2 * xo + c) * (size_t)C;
         }
     } else {
-        src[0] = x + row * (size_t)dim;
+        src[0] = x + rr * (size_t)dim;
     }
-    float v[V];
+    f32x4 v[V];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        const int c = lane + 64 * i;
-        float t = 0.f;
-        if (c < dim) t = MERGE ? src[c / C][c % C] : src[0][c];
+        const int c = (sub + LPR * i) * 4;
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (c < dim) t = MERGE ? *(const f32x4 *)(src[c / C] + c % C) : *(const f32x4 *)(src[0] + c);
         v[i] = t;
-        sum += t;
+        sum += (t[0] + t[1]) + (t[2] + t[3]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float mean = sum / (float)dim;
     float var = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        const float d = v[i] - mean;
-        var += (lane + 64 * i < dim) ? d * d : 0.f;
+        if ((sub + LPR * i) * 4 < dim) {
+            const f32x4 d = v[i] - mean;
+            var += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    for (int o = LPR / 2; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
     const float rstd = rsqrtf(var / (float)dim + eps);
+    if (!live) return;
     E *dst = y + row * (size_t)ldy;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-        const int c = lane + 64 * i;
-        if (c < dim)
-            dst[c] = (E)((v[i] - mean) * rstd * g[c] + be[c]);
-        else if (c < ldy)
-            dst[c] = (E)0.f;
+        const int c = (sub + LPR * i) * 4;
+        if (c < dim) {
+            const f32x4 gg = *(const f32x4 *)(g + c), bb = *(const f32x4 *)(be + c);
+            store4<E>(dst + c, (v[i] - mean) * rstd * gg + bb);
+        } else if (c < ldy) {
+            store4<E>(dst + c, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
     }
-    if (64 * V < ldy)
-        for (int c = 64 * V + lane; c < ldy; c += 64) dst[c] = (E)0.f;
+    for (int c = (sub + LPR * V) * 4; c < ldy; c += LPR * 4) store4<E>(dst + c, f32x4{0.f, 0.f, 0.f, 0.f});
 }
 
 template <class E, bool MERGE>
 static hipError_t launch_swin_ln_e(const float *x, const float *g, const float *be, E *y, size_t rows, int dim, int ldy,
                                    float eps, int Hin, int Win, hipStream_t s) {
-    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    const int V = (dim + 63) / 64;
-#define OCM_LN_CASE(v)                                                                                       \
-    if (V <= v) {                                                                                            \
-        swin_ln_kernel<E, MERGE, v><<<grid, block, 0, s>>>(x, g, be, y, rows, dim, ldy, eps, Hin, Win);      \
-        return hipGetLastError();                                                                            \
+    if (dim % 4 || ldy % 4 || (MERGE && (dim / 4) % 4)) return hipErrorInvalidValue;
+    const dim3 block(256);
+#define OCM_LN_CASE(lpr, v)                                                                                         \
+    if (dim <= lpr * v * 4) {                                                                                       \
+        const dim3 grid((unsigned)((rows + 4 * (64 / lpr) - 1) / (4 * (64 / lpr))));                                 \
+        swin_ln_kernel<E, MERGE, lpr, v><<<grid, block, 0, s>>>(x, g, be, y, rows, dim, ldy, eps, Hin, Win);        \
+        return hipGetLastError();                                                                                   \
     }
-    OCM_LN_CASE(2) OCM_LN_CASE(3) OCM_LN_CASE(6) OCM_LN_CASE(12) OCM_LN_CASE(24)
+    OCM_LN_CASE(32, 1) OCM_LN_CASE(64, 1) OCM_LN_CASE(64, 2) OCM_LN_CASE(64, 3) OCM_LN_CASE(64, 6)
 #undef OCM_LN_CASE
     return hipErrorInvalidValue;
 }
