@@ -11,7 +11,7 @@
 // every epilogue.
 //
 // Staging is register-staged with the issue-early / commit-late split and one LDS-only barrier per
-// step. When K is a compile-time constant (KSTEPS > 0, even) two register slots give a prefetch
+// step. When K is a compile-time constant (KSTEPS > 0) two register slots give a prefetch
 // distance of two steps with an unconditional load stream, so hipcc counts its own `vmcnt(N)` waits.
 //
 // The A operand comes through a loader policy so the same main loop serves
@@ -190,27 +190,42 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
         }
     }
 
-    if constexpr (KSTEPS > 0 && KSTEPS % 2 == 0) {
-        // Two register slots: the tile committed to LDS in step t was requested in step t-2 (L2 latency
-        // under load is ~1 us, more than one step). The stream is unconditional (indices past the end
-        // re-read the last tile into a dead slot) and the trip count is a constant, so hipcc counts its
-        // own `s_waitcnt vmcnt(N)` instead of draining to 0.
+    if constexpr (KSTEPS > 0) {
+        // Two register slots (s0: even steps, s1: odd steps): the tile committed to LDS in step t was requested
+        // in step t-2 (L2 latency under load is ~1 us, more than one step). The stream is unconditional (indices
+        // past the end re-read the last tile into a dead slot) and the loop is fully unrolled with a constant
+        // trip count, so hipcc counts its own `s_waitcnt vmcnt(N)` instead of draining to 0.
         auto issue2 = [&](Slot &sl, int t) { issue(sl, min(t, KSTEPS - 1) * KROW); };
         Slot s0, s1;
         issue2(s0, 0);
         issue2(s1, 1);
         commit(0, s0);
-        issue2(s0, 2);  // s1 = tile 1, s0 = tile 2
+        issue2(s0, 2);
         lds_barrier();
-        for (int t = 0; t < KSTEPS; t += 2) {
-            compute(0);     // tile t (even tiles live in buffer 0)
-            commit(1, s1);  // tile t+1
-            issue2(s1, t + 3);
-            lds_barrier();
-            compute(1);     // tile t+1
-            commit(0, s0);  // tile t+2 (a dead duplicate after the last tile)
-            issue2(s0, t + 4);
-            lds_barrier();
+        if constexpr (KSTEPS % 2 == 0) {
+            for (int t = 0; t < KSTEPS; t += 2) {
+                compute(0);     // step t (even steps live in buffer 0)
+                commit(1, s1);  // step t+1
+                issue2(s1, t + 3);
+                lds_barrier();
+                compute(1);     // step t+1
+                commit(0, s0);  // step t+2 (a dead duplicate after the last step)
+                issue2(s0, t + 4);
+                lds_barrier();
+            }
+        } else {  // small odd step counts (K = 192 bf16, K = 96 fp32): fully unrolled
+#pragma unroll
+            for (int t = 0; t < KSTEPS; ++t) {
+                compute(t & 1);  // step t lives in buffer t & 1
+                if (t & 1) {
+                    if (t + 1 < KSTEPS) commit(0, s0);  // step t+1
+                    issue2(s0, t + 3);
+                } else {
+                    if (t + 1 < KSTEPS) commit(1, s1);
+                    issue2(s1, t + 3);
+                }
+                lds_barrier();
+            }
         }
     } else {
         // runtime K: one-step prefetch

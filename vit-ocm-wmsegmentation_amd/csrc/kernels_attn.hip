@@ -336,8 +336,7 @@ __global__ __launch_bounds__(512, 4) void attn_small_kernel(const bf16 *__restri
 
 static hipError_t launch_attention_bf16(const bf16 *q, const bf16 *k, const bf16 *vt, bf16 *ctx, float *lse2, int batch,
                                         int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
-    static const char *force_stream = getenv("OCM_ATTN_STREAM");  // development switch
-    if (n_tokens <= 256 && !force_stream) {
+    if (n_tokens <= 256) {
         const dim3 grid(batch * heads), block(512);
         if (ctx)
             attn_small_kernel<true><<<grid, block, 0, s>>>(q, k, vt, ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);

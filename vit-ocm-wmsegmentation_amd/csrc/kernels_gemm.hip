@@ -111,6 +111,7 @@ static hipError_t launch_gemm(const ALoad &al, const E *w, int64_t ldw, int M, i
     if (K % Elem<E>::KROW) return hipErrorInvalidValue;
     switch (K / Elem<E>::KROW) {
         case 2: return launch_gemm_ks<Cfg, E, SWAP, 2>(al, w, ldw, M, N, K, epi, s);  // Swin stage 0 (K = 96 padded)
+        case 3: return launch_gemm_ks<Cfg, E, SWAP, 3>(al, w, ldw, M, N, K, epi, s);  // Swin stage 1 (K = 192 bf16, 96 fp32)
         case 4: return launch_gemm_ks<Cfg, E, SWAP, 4>(al, w, ldw, M, N, K, epi, s);
         case 6: return launch_gemm_ks<Cfg, E, SWAP, 6>(al, w, ldw, M, N, K, epi, s);
         case 12: return launch_gemm_ks<Cfg, E, SWAP, 12>(al, w, ldw, M, N, K, epi, s);
