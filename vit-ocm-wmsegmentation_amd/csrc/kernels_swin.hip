@@ -199,8 +199,10 @@ hipError_t launch_swin_ln(int prec, const float *x, const float *g, const float 
 
 // ------------------------------------------------------------------------------------------
 // relative-position bias (SwinRelativePositionBias :329-370) in the attention kernels' order, times log2(e):
-//   out[head][qt][lane][sub*16 + e] = table[index(i, j)][head] * log2e,  i = qt*32 + (lane & 31),
-//   j = sub*32 + key_of_reg(e, lane >> 5); keys j >= ws*ws get -1e30 (the padding mask), queries i >= ws*ws 0.
+//   out[head][qt][c][lane][e4] = table[index(i, j)][head] * log2e,  c = sub*4 + e/4, e4 = e%4 (16 accumulator
+//   registers e per key half `sub`), i = qt*32 + (lane & 31), j = sub*32 + key_of_reg(e, lane >> 5): one 16-B load
+//   per lane and chunk c, 1 KiB contiguous per wavefront. Keys j >= ws*ws get -1e30 (the padding mask), queries
+//   i >= ws*ws 0.
 // `dense` (optional) receives the plain [head][ws*ws][ws*ws] table (natural-log domain) for the fp32 kernel.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void swin_bias_perm_kernel(const float *__restrict__ table, float *__restrict__ perm,
@@ -208,8 +210,8 @@ __global__ __launch_bounds__(256) void swin_bias_perm_kernel(const float *__rest
     const int A = ws * ws;
     const int total = heads * 2 * 64 * 32;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
-        const int e32 = idx & 31, lane = (idx >> 5) & 63, qt = (idx >> 11) & 1, head = idx >> 12;
-        const int sub = e32 >> 4, e = e32 & 15;
+        const int e4 = idx & 3, lane = (idx >> 2) & 63, c8 = (idx >> 8) & 7, qt = (idx >> 11) & 1, head = idx >> 12;
+        const int sub = c8 >> 2, e = (c8 & 3) * 4 + e4;
         const int i = qt * 32 + (lane & 31), j = sub * 32 + key_of_reg(e, lane >> 5);
         float v = 0.f;
         if (j >= A) {
@@ -279,23 +281,35 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
     const int A = g.ws * g.ws, C = g.heads * 32;
     const bf16 *base = qkv + head * 32;
 
-    // stage K rows and V^T columns of the window (padding keys: exact zeros)
+    // All global loads of the wave are issued in one burst (K / V rows of the window's tokens, the Q fragments of
+    // both query tiles), then K rows and V^T columns go to LDS (padding keys: exact zeros).
+    bf16x8 kreg[4], vreg[4], qf[2][2];
+    size_t qtok[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = lane + 64 * i, key = idx >> 2, ch = idx & 3;
-        bf16x8 kv, vv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) kv[e] = vv[e] = (bf16)0.f;
+        for (int e = 0; e < 8; ++e) kreg[i][e] = vreg[i][e] = (bf16)0.f;
         if (key < A) {
             const bf16 *row = base + win_token(g, b, wy, wx, key) * (size_t)ld + ch * 8;
-            kv = *(const bf16x8 *)(row + C);
-            vv = *(const bf16x8 *)(row + 2 * C);
+            kreg[i] = *(const bf16x8 *)(row + C);
+            vreg[i] = *(const bf16x8 *)(row + 2 * C);
         }
-        *(bf16x8 *)(Ks + key * 64 + ch * 16) = kv;
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        qtok[qt] = win_token(g, b, wy, wx, min(qt * 32 + r, A - 1));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) qf[qt][s] = *(const bf16x8 *)(base + qtok[qt] * (size_t)ld + 16 * s + 8 * h);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = lane + 64 * i, key = idx >> 2, ch = idx & 3;
+        *(bf16x8 *)(Ks + key * 64 + ((ch ^ ((key >> 2) & 3)) << 4)) = kreg[i];  // chunk swizzle: conflict-free b128 reads
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int d = ch * 8 + e;
-            *(bf16 *)(Vs + lds_off(d, key >> 3) + (key & 7) * 2) = vv[e];
+            *(bf16 *)(Vs + lds_off(d, key >> 3) + (key & 7) * 2) = vreg[i][e];
         }
     }
     const bool masked = g.shift > 0 && (wy == g.H / g.ws - 1 || wx == g.nWx - 1);  // wave-uniform
@@ -304,15 +318,11 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 
     const int pr = pi_row(r);
-    const float *bp = bias_perm + (size_t)head * 2 * 64 * 32 + lane * 32;
-#pragma unroll 1
+    const float *bp = bias_perm + (size_t)head * 2 * 64 * 32 + lane * 4;
+#pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         if (qt * 32 >= A) break;
         const int qi = qt * 32 + r;
-        const size_t qtok = win_token(g, b, wy, wx, min(qi, A - 1));
-        bf16x8 qf[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) qf[s] = *(const bf16x8 *)(base + qtok * (size_t)ld + 16 * s + 8 * h);
         f32x16 S[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -320,8 +330,8 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
             for (int e = 0; e < 16; ++e) S[sub][e] = 0.f;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16x8 a = *(const bf16x8 *)(Ks + (sub * 32 + pr) * 64 + (2 * s + h) * 16);
-                S[sub] = mfma32(a, qf[s], S[sub]);
+                const bf16x8 a = *(const bf16x8 *)(Ks + (sub * 32 + pr) * 64 + (((2 * s + h) ^ ((pr >> 2) & 3)) << 4));
+                S[sub] = mfma32(a, qf[qt][s], S[sub]);
             }
         }
         const float *bq = bp + qt * 64 * 32;
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
-                const f32x4 bv = *(const f32x4 *)(bq + sub * 16 + e4 * 4);
+                const f32x4 bv = *(const f32x4 *)(bq + (sub * 4 + e4) * 256);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = fmaf(S[sub][e4 * 4 + e], scale2, bv[e]);
@@ -367,15 +377,36 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
                 const bf16x8 a = *(const bf16x8 *)(Vs + lds_off(r, 4 * sub + 2 * s2 + h));
                 O = mfma32(a, pb, O);
             }
-        if (qi < A) {
+        // Lane (r, h) holds dims {8g + 4h + e}: trade half of them with lane (r, h ^ 1) so that each lane owns 16
+        // consecutive dims and the two lanes of a query write one contiguous 64-byte row segment.
+        {
             const float inv = 1.0f / l;
-            bf16 *dst = ctx + qtok * (size_t)ldc + head * 32;
+            uint32_t pk[8];  // pk[2g], pk[2g+1]: dims 8g + 4h + {0,1}, {2,3} as packed bf16
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                bf16x4 o;
+            for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (bf16)(O[4 * gq + e] * inv);
-                *(bf16x4 *)(dst + 8 * gq + 4 * h) = o;
+                for (int e = 0; e < 2; ++e) {
+                    bf16x2 t;
+                    t[0] = (bf16)(O[4 * gq + 2 * e] * inv);
+                    t[1] = (bf16)(O[4 * gq + 2 * e + 1] * inv);
+                    pk[2 * gq + e] = __builtin_bit_cast(uint32_t, t);
+                }
+            uint32_t out[8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {  // h = 0 sends groups 2, 3 and keeps 0, 1; h = 1 the other way round
+                const uint32_t send = h ? pk[k] : pk[4 + k];
+                const uint32_t recv = (uint32_t)__shfl_xor((int)send, 32, 64);
+                const uint32_t keep = h ? pk[4 + k] : pk[k];
+                // h = 0: dims [0..3]=keep g0, [4..7]=recv g0, [8..11]=keep g1, [12..15]=recv g1
+                // h = 1: dims [16..19]=recv g2, [20..23]=keep g2, [24..27]=recv g3, [28..31]=keep g3
+                const int gsel = k >> 1, w = k & 1;
+                out[4 * gsel + (h ? 2 : 0) + w] = keep;
+                out[4 * gsel + (h ? 0 : 2) + w] = recv;
+            }
+            if (qi < A) {
+                bf16 *dst = ctx + qtok[qt] * (size_t)ldc + head * 32 + 16 * h;
+                *(uint4 *)dst = uint4{out[0], out[1], out[2], out[3]};
+                *(uint4 *)(dst + 8) = uint4{out[4], out[5], out[6], out[7]};
             }
         }
     }
