@@ -100,8 +100,13 @@ enum {
                                    dropped: (B,H,n_rows,N-1)          (utils.py:229-233)            */
     OCM_LAST_ATTN_ONLY = 1 << 5,/* get_last_selfattention (:239-246): the last block stops after
                                    its attention probabilities; FEAT/TOKENS/QKV must not be set.    */
-    OCM_OUT_FMAP = 1 << 6       /* norm(x)[:, 1:] as a (B,D,hp,wp) feature map — what the encoders of
+    OCM_OUT_FMAP = 1 << 6,      /* norm(x)[:, 1:] as a (B,D,hp,wp) feature map — what the encoders of
                                    model.py:48-53,134-139 return                                   */
+    OCM_USE_GRAPH = 1 << 7      /* launch through a cached hipGraph: the forward's ~80 kernel launches are
+                                   captured once and replayed with one hipGraphLaunch while shapes, flags
+                                   and every pointer in the io block stay the same (the steady state of the
+                                   reference's one-tile-per-call loops); otherwise the graph is re-captured
+                                   and updated in place. Same results, less host time per call.        */
 };
 
 /* One batch of tiles through prepare_tokens + blocks [+ final norm].
@@ -147,6 +152,9 @@ size_t ocm_vit_workspace_bytes(const ocm_vit_t *h, int32_t batch, int32_t n_toke
 /* VisionTransformer.get_intermediate_feat / get_last_selfattention / forward_feats /
  * get_intermediate_layers (vision_transformer.py:211-256), selected by io->flags. */
 int ocm_vit_forward(ocm_vit_t *h, const ocm_vit_io *io);
+
+/* Counters of the OCM_USE_GRAPH path: forwards replayed from the cached graph / graph (re-)captures. */
+int ocm_vit_graph_stats(const ocm_vit_t *h, uint64_t *replays, uint64_t *captures);
 
 /* VisionTransformer.prepare_tokens (:198-209): patch embedding + cls + pos.
  * Uses image/strides/origins/batch/tile_*, pos_embed and stream of `io`;

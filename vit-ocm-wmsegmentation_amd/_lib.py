@@ -24,6 +24,7 @@ OCM_OUT_TOKENS = 1 << 3
 OCM_OUT_ROWS = 1 << 4
 OCM_LAST_ATTN_ONLY = 1 << 5
 OCM_OUT_FMAP = 1 << 6
+OCM_USE_GRAPH = 1 << 7
 
 KERNEL_CLASSES = ("patch_embed", "layernorm", "qkv_gemm", "attention", "attn_probs", "proj_gemm", "fc1_gemm",
                   "fc2_gemm")
@@ -125,6 +126,7 @@ SIGNATURES = {
     "ocm_op_normalize_u8": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ocm_otsu_threshold": (_i32, [C.POINTER(C.c_uint64), _i64]),
     "ocm_op_threshold_u8": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "ocm_vit_graph_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "ocm_swin_create": (C.c_int, [C.POINTER(OcmSwinConfig), C.POINTER(C.c_void_p)]),
     "ocm_swin_destroy": (None, [C.c_void_p]),
     "ocm_swin_set_param": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),

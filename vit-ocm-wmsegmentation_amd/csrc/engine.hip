@@ -121,6 +121,13 @@ struct ocm_vit {
     int cls, pe_w, pe_b, norm_g, norm_b, mask_tok;
     char *arena;
     size_t arena_bytes;
+    // OCM_USE_GRAPH: the launch sequence of the last forward as an instantiated hipGraph, keyed on every value
+    // the kernels' arguments were derived from (shapes, flags, pointers)
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t graph_stream = nullptr;  // stands in for the (uncapturable) legacy default stream
+    ocm_vit_io graph_key;
+    bool graph_valid = false;
+    uint64_t graph_hits = 0, graph_captures = 0;
 
     int add(const std::string &name, ParamKind kind, size_t count, size_t stored_elems) {
         Param pr{name, kind, count, arena_bytes, false};
@@ -193,6 +200,8 @@ extern "C" int ocm_vit_create(const ocm_vit_config *cfg, ocm_vit_t **out) {
 
 extern "C" void ocm_vit_destroy(ocm_vit_t *h) {
     if (!h) return;
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph_stream) (void)hipStreamDestroy(h->graph_stream);
     if (h->arena) (void)hipFree(h->arena);
     delete h;
 }
@@ -387,29 +396,11 @@ extern "C" int ocm_vit_final_norm(ocm_vit_t *h, const float *x, float *y, int64_
     return OCM_OK;
 }
 
-extern "C" int ocm_vit_forward(ocm_vit_t *h, const ocm_vit_io *io) {
-    if (!h) return fail(OCM_EINVAL, "null handle");
-    int rc = ocm_vit_params_ready(h);
-    if (rc) return rc;
-    int n = 0;
-    if ((rc = check_tiles(h, io, &n))) return rc;
+// The launch sequence of one forward (arguments already validated by ocm_vit_forward).
+static int enqueue_forward(ocm_vit *h, const ocm_vit_io *io, int n, hipStream_t s) {
     const int fl = io->flags, B = io->batch, L = h->L;
     const bool attn_only = fl & OCM_LAST_ATTN_ONLY;
-    if (io->n_last < 1 || io->n_last > L) return fail(OCM_EINVAL, "n_last %d out of range [1,%d]", io->n_last, L);
-    if (attn_only && (fl & (OCM_OUT_FEAT | OCM_OUT_TOKENS | OCM_OUT_QKV | OCM_OUT_FMAP)))
-        return fail(OCM_EINVAL, "OCM_LAST_ATTN_ONLY excludes FEAT/TOKENS/QKV/FMAP outputs");
-    if ((fl & OCM_OUT_FMAP) && !io->out_fmap) return fail(OCM_EINVAL, "OCM_OUT_FMAP without out_fmap");
-    if ((fl & OCM_OUT_FMAP) && (size_t)h->M * h->esz < (size_t)h->D * 4)
-        return fail(OCM_EINVAL, "OCM_OUT_FMAP needs mlp_hidden*esz >= 4*embed_dim (scratch for the normed tokens)");
-    if (attn_only && io->n_last != 1) return fail(OCM_EINVAL, "OCM_LAST_ATTN_ONLY requires n_last == 1");
-    if ((fl & OCM_OUT_FEAT) && !io->out_feat) return fail(OCM_EINVAL, "OCM_OUT_FEAT without out_feat");
-    if ((fl & OCM_OUT_ATTN) && !io->out_attn) return fail(OCM_EINVAL, "OCM_OUT_ATTN without out_attn");
-    if ((fl & OCM_OUT_QKV) && !io->out_qkv) return fail(OCM_EINVAL, "OCM_OUT_QKV without out_qkv");
-    if ((fl & OCM_OUT_TOKENS) && !io->out_tokens) return fail(OCM_EINVAL, "OCM_OUT_TOKENS without out_tokens");
-    if ((fl & OCM_OUT_ROWS) && (!io->out_rows || io->n_rows <= 0))
-        return fail(OCM_EINVAL, "OCM_OUT_ROWS needs out_rows and n_rows > 0");
-    if ((rc = check_ws(h, B, n, io->workspace, io->workspace_bytes))) return rc;
-    hipStream_t s = (hipStream_t)io->stream;
+    int rc;
     const Workspace w = carve(h, B, n, (char *)io->workspace);
     if ((rc = run_prepare(h, io, w.x, n, s))) return rc;
     const size_t T = (size_t)B * n;
@@ -435,6 +426,98 @@ extern "C" int ocm_vit_forward(ocm_vit_t *h, const ocm_vit_io *io) {
                                  h->cfg.ln_eps, s));
         HIP_TRY(launch_tokens_to_fmap(yn, io->out_fmap, B, n, h->D, s));
     }
+    return OCM_OK;
+}
+
+extern "C" int ocm_vit_forward(ocm_vit_t *h, const ocm_vit_io *io) {
+    if (!h) return fail(OCM_EINVAL, "null handle");
+    int rc = ocm_vit_params_ready(h);
+    if (rc) return rc;
+    int n = 0;
+    if ((rc = check_tiles(h, io, &n))) return rc;
+    const int fl = io->flags, B = io->batch, L = h->L;
+    const bool attn_only = fl & OCM_LAST_ATTN_ONLY;
+    if (io->n_last < 1 || io->n_last > L) return fail(OCM_EINVAL, "n_last %d out of range [1,%d]", io->n_last, L);
+    if (attn_only && (fl & (OCM_OUT_FEAT | OCM_OUT_TOKENS | OCM_OUT_QKV | OCM_OUT_FMAP)))
+        return fail(OCM_EINVAL, "OCM_LAST_ATTN_ONLY excludes FEAT/TOKENS/QKV/FMAP outputs");
+    if ((fl & OCM_OUT_FMAP) && !io->out_fmap) return fail(OCM_EINVAL, "OCM_OUT_FMAP without out_fmap");
+    if ((fl & OCM_OUT_FMAP) && (size_t)h->M * h->esz < (size_t)h->D * 4)
+        return fail(OCM_EINVAL, "OCM_OUT_FMAP needs mlp_hidden*esz >= 4*embed_dim (scratch for the normed tokens)");
+    if (attn_only && io->n_last != 1) return fail(OCM_EINVAL, "OCM_LAST_ATTN_ONLY requires n_last == 1");
+    if ((fl & OCM_OUT_FEAT) && !io->out_feat) return fail(OCM_EINVAL, "OCM_OUT_FEAT without out_feat");
+    if ((fl & OCM_OUT_ATTN) && !io->out_attn) return fail(OCM_EINVAL, "OCM_OUT_ATTN without out_attn");
+    if ((fl & OCM_OUT_QKV) && !io->out_qkv) return fail(OCM_EINVAL, "OCM_OUT_QKV without out_qkv");
+    if ((fl & OCM_OUT_TOKENS) && !io->out_tokens) return fail(OCM_EINVAL, "OCM_OUT_TOKENS without out_tokens");
+    if ((fl & OCM_OUT_ROWS) && (!io->out_rows || io->n_rows <= 0))
+        return fail(OCM_EINVAL, "OCM_OUT_ROWS needs out_rows and n_rows > 0");
+    if ((rc = check_ws(h, B, n, io->workspace, io->workspace_bytes))) return rc;
+    hipStream_t s = (hipStream_t)io->stream;
+    if (!(fl & OCM_USE_GRAPH) || g_prof.on) return enqueue_forward(h, io, n, s);
+
+    // ---- hipGraph path: replay when nothing the launch arguments depend on has changed --------------------
+    // The legacy default stream (what torch uses unless told otherwise) cannot be captured: capture and replay on
+    // a BLOCKING stream of our own instead, which the default stream orders itself with implicitly on both sides.
+    if (s == nullptr) {
+        if (!h->graph_stream && hipStreamCreateWithFlags(&h->graph_stream, hipStreamDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return enqueue_forward(h, io, n, s);
+        }
+        s = h->graph_stream;
+    }
+    ocm_vit_io key = *io;
+    key.reserved = 0;
+    if (h->graph_valid && memcmp(&key, &h->graph_key, sizeof key) == 0) {
+        ++h->graph_hits;
+        HIP_TRY(hipGraphLaunch(h->graph_exec, s));
+        return OCM_OK;
+    }
+    // (Re-)capture the launch sequence on the caller's stream; nothing executes during capture.
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return enqueue_forward(h, io, n, s);  // stream cannot be captured (e.g. already capturing): plain launches
+    }
+    rc = enqueue_forward(h, io, n, s);
+    const hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (rc || ce != hipSuccess || !graph) {  // capture refused something: nothing ran, so run it the plain way
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        h->graph_valid = false;
+        return enqueue_forward(h, io, n, s);
+    }
+    ++h->graph_captures;
+    h->graph_valid = false;
+    bool have_exec = false;
+    if (h->graph_exec) {  // same topology, new arguments: update the instantiated graph in place
+        hipGraphNode_t err_node = nullptr;
+        hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
+        if (hipGraphExecUpdate(h->graph_exec, graph, &err_node, &res) == hipSuccess && res == hipGraphExecUpdateSuccess) {
+            have_exec = true;
+        } else {
+            (void)hipGetLastError();  // clear the sticky error of the failed update
+            (void)hipGraphExecDestroy(h->graph_exec);
+            h->graph_exec = nullptr;
+        }
+    }
+    if (!have_exec) {
+        hipError_t ie = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) {
+            (void)hipGraphDestroy(graph);
+            h->graph_exec = nullptr;
+            return fail(OCM_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(ie));
+        }
+    }
+    (void)hipGraphDestroy(graph);
+    h->graph_key = key;
+    h->graph_valid = true;
+    HIP_TRY(hipGraphLaunch(h->graph_exec, s));
+    return OCM_OK;
+}
+
+extern "C" int ocm_vit_graph_stats(const ocm_vit_t *h, uint64_t *replays, uint64_t *captures) {
+    if (!h) return fail(OCM_EINVAL, "null handle");
+    if (replays) *replays = h->graph_hits;
+    if (captures) *captures = h->graph_captures;
     return OCM_OK;
 }
 
