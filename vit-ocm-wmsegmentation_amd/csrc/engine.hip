@@ -314,7 +314,9 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     const int pc = h->prec;
     // y = attn(norm1(x))
     { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, !pc, T, D, eps, s)); }
-    { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, w.vt, out_qkv, batch, n, np, H, s)); }
+    // a block that stops after its probabilities (get_last_selfattention) and returns no qkv never reads V
+    void *vt_dst = (attn_only && !out_qkv) ? nullptr : w.vt;
+    { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, vt_dst, out_qkv, batch, n, np, H, s)); }
     if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s)); }
     if (attn_only) {
         if (out_attn) {

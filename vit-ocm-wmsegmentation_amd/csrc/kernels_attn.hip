@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16 *__restrict__ 
             bf16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
-            if (key0 < npad) {
+            if (WANT_O && key0 < npad) {  // the statistics-only variant never touches V^T
                 v = *(const bf16x8 *)(Vb + (int64_t)row * npad + key0);
                 if (key0 + 8 > N) {  // keys >= N are padding: force exact zeros (0 * garbage must not be NaN)
 #pragma unroll
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(512, 4) void attn_small_kernel(const bf16 *__restri
             bf16x8 v;
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
-            if (key0 < npad) {
+            if (WANT_O && key0 < npad) {  // the statistics-only variant never touches V^T
                 v = *(const bf16x8 *)(Vb + (int64_t)d * npad + key0);
                 if (key0 + 8 > N) {  // padding keys must be exact zeros: P = 0 times garbage may be NaN
 #pragma unroll

@@ -264,7 +264,9 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader<E> al, const E *
                                                       EpiQK<E> eqk, EpiVt<E> ev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = 3 * D, K = D;
-    const int tiles_n = N / Cfg::BN;  // D % BN == 0 is checked by the launcher
+    // D % BN == 0 is checked by the launcher; without a V^T destination (a block that stops after its
+    // attention probabilities) the V third of the projection is not computed at all
+    const int tiles_n = (ev.vt ? N : 2 * D) / Cfg::BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
@@ -289,7 +291,7 @@ static hipError_t launch_qkv_ks(const RowLoader<E> &al, const E *w, int M, int D
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * (3 * D / Cfg::BN);
+    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((ev.vt ? 3 : 2) * D / Cfg::BN);
     kern<<<dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, s>>>(al, w, M, D, eqk, ev);
     return hipGetLastError();
 }
