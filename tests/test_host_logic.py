@@ -163,3 +163,20 @@ def test_trunc_normal_statistics():
     assert abs(t.mean().item()) < 2e-4 and abs(t.std().item() - 0.02) < 2e-4 and t.abs().max().item() < 0.12
     u = trunc_normal_(torch.empty(20000), mean=0., std=1., a=-1., b=1.)
     assert u.min().item() >= -1 and u.max().item() <= 1
+
+
+def test_missing_extension_fails_loudly(tmp_path):
+    """Without libocm_vit.so the compute path raises at load time — there is no Python / torch fallback to hide
+    behind (checked in a fresh interpreter with OCM_VIT_LIB pointing at a file that does not exist)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from vit_ocm_wmsegmentation_amd import _lib\n"
+            "try:\n"
+            "    _lib.load()\n"
+            "except _lib.OcmError as e:\n"
+            "    assert 'not built' in str(e) and 'no CPU' in str(e).replace('There is no CPU', 'no CPU'), str(e)\n"
+            "    print('LOUD')\n" % ROOT)
+    env = dict(os.environ, OCM_VIT_LIB=str(tmp_path / "absent.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "LOUD" in out.stdout, out.stdout + out.stderr
