@@ -9,6 +9,9 @@
 #include "launch.h"
 
 typedef GemmCfg<128, 128, 2, 2> Cfg128x128;
+// the qkv projection runs the same tile with 8 waves (32x64 MFMA sub-tiles per wave): two waves per SIMD inside
+// one workgroup overlap its heavier scatter epilogue with the other waves' MFMAs (29.0 -> 25.8 us at ViT-S, B=64)
+typedef GemmCfg<128, 128, 2, 4> Cfg128x128q;
 typedef GemmCfg<64, 128, 2, 2> Cfg64x128;
 typedef GemmCfg<64, 64, 2, 2> Cfg64x64;
 // 8 waves, one workgroup per CU: half the L2->LDS bytes per output element of 128x128. Pays off once the
@@ -318,7 +321,7 @@ static hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, 
     if constexpr (sizeof(E) == 2)
         if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_cfg<Cfg256x256, E>(al, w, M, D, eqk, ev, s);
     const long t128 = (long)((M + 127) / 128) * (3 * D / 128);
-    if (D % 128 == 0 && t128 >= 512) return launch_qkv_cfg<Cfg128x128, E>(al, w, M, D, eqk, ev, s);
+    if (D % 128 == 0 && t128 >= 512) return launch_qkv_cfg<Cfg128x128q, E>(al, w, M, D, eqk, ev, s);
     if (D % 128 == 0) return launch_qkv_cfg<Cfg64x128, E>(al, w, M, D, eqk, ev, s);
     return launch_qkv_cfg<Cfg64x64, E>(al, w, M, D, eqk, ev, s);
 }
