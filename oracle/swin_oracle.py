@@ -7,7 +7,6 @@ transformers/models/swin/modeling_swin.py (line numbers of 5.15.0 cited per func
 package by oracle/make_golden_swin.py (max |diff| recorded in tests/golden/swin_*.npz). Nothing in the product
 imports this file.
 """
-import math
 
 import torch
 import torch.nn.functional as F

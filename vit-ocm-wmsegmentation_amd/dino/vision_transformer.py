@@ -13,7 +13,6 @@ No forward below calls their ATen kernels; every method packs device pointers an
 (include/ocm_vit.h). Inputs must be on a HIP device — there is deliberately no CPU fallback
 (the CPU statement of this arithmetic is the test oracle under oracle/).
 """
-import ctypes as C
 import math
 from functools import partial
 

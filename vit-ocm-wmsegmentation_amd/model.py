@@ -12,7 +12,6 @@ decoders run token-major as one MFMA GEMM + a pixel-shuffle kernel. Inference on
 never differentiated. The reference initialises mask_token with timm's trunc_normal_; here the package's
 own trunc_normal_ (dino/utils.py) with the same bounds is used.
 """
-import ctypes as C
 import os
 from functools import partial
 
