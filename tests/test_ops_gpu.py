@@ -52,7 +52,9 @@ def test_cast_bf16(lib, dev):
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (12608, 1536, 384), (333, 384, 1536), (70, 96, 192),
-                                   (12608, 384, 384), (64, 192, 64)])
+                                   (12608, 384, 384), (64, 192, 64),
+                                   (3000, 288, 128), (2100, 96, 128), (500, 192, 192),  # Swin: N tails, K of 2 / 3 steps
+                                   (32768, 1024, 768)])  # 512 tiles of 256x256: the 8-wave tile + banded epilogue
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_linear(lib, dev, M, N, K, epi):
     a = _rand((M, K), dev, 10).to(torch.bfloat16)
@@ -85,7 +87,8 @@ def _qkv_inputs(dev, B, N, H):
     return a, w, bias
 
 
-@pytest.mark.parametrize("B,N,H", [(3, 197, 6), (2, 17, 2), (1, 577, 12), (5, 50, 3)])
+@pytest.mark.parametrize("B,N,H", [(3, 197, 6), (2, 17, 2), (1, 577, 12), (5, 50, 3),
+                                   (26, 577, 12)])  # 531 tiles of 256x256: big-tile q/k and transposed V^T epilogues
 def test_qkv_proj(lib, dev, B, N, H):
     D = H * 64
     a, w, bias = _qkv_inputs(dev, B, N, H)
