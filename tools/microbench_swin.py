@@ -38,4 +38,4 @@ for H, heads in ((56, 3), (28, 6), (14, 12), (7, 24)):
         torch.cuda.synchronize()
         us = a.elapsed_time(b) / 10 * 1e3
         mb = (T * 3 * Cc * 2 + T * Cc * 2) / 1e6
-        print(f"grid {H}x{H} heads {heads} shift {shift}: {us:8.1f} us  ({mb:.0f} MB -> {mb / us * 1e-6 * 1e6 / 1e6:.2f} TB/s)", flush=True)
+        print(f"grid {H}x{H} heads {heads} shift {shift}: {us:8.1f} us  ({mb:.0f} MB -> {mb / us:.2f} TB/s)", flush=True)

@@ -246,18 +246,19 @@ struct WinGeom {
 // token (row of the (B, H*W, C) stream) of position p of window (b, wy, wx): the window tiles the image rolled
 // by -shift (cyclic_shift :617-626 + window_partition :486-495), so its source pixel is (+shift) mod size; the
 // output goes back to the same token (window_reverse + reverse roll).
-__device__ __forceinline__ size_t win_token(const WinGeom &g, int b, int wy, int wx, int p) {
-    const int py = p / g.ws, px = p - py * g.ws;
-    int y = wy * g.ws + py + g.shift, x = wx * g.ws + px + g.shift;
+// (`ws` is passed separately: a compile-time 7 in the Swin-T instantiation turns the divisions into multiplies)
+__device__ __forceinline__ size_t win_token(const WinGeom &g, int ws, int b, int wy, int wx, int p) {
+    const int py = p / ws, px = p - py * ws;
+    int y = wy * ws + py + g.shift, x = wx * ws + px + g.shift;
     if (y >= g.H) y -= g.H;
     if (x >= g.W) x -= g.W;
     return ((size_t)b * g.H + y) * g.W + x;
 }
 // region id of get_attn_mask (:584-607) for position p of the window, in the SHIFTED frame
-__device__ __forceinline__ int win_region(const WinGeom &g, int wy, int wx, int p) {
-    const int py = p / g.ws, px = p - py * g.ws;
-    const int ys = wy * g.ws + py, xs = wx * g.ws + px;
-    const int ry = (ys >= g.H - g.ws) + (ys >= g.H - g.shift), rx = (xs >= g.W - g.ws) + (xs >= g.W - g.shift);
+__device__ __forceinline__ int win_region(const WinGeom &g, int ws, int wy, int wx, int p) {
+    const int py = p / ws, px = p - py * ws;
+    const int ys = wy * ws + py, xs = wx * ws + px;
+    const int ry = (ys >= g.H - ws) + (ys >= g.H - g.shift), rx = (xs >= g.W - ws) + (xs >= g.W - g.shift);
     return ry * 3 + rx;
 }
 
@@ -265,6 +266,7 @@ __device__ __forceinline__ int win_region(const WinGeom &g, int wy, int wx, int 
 // S^T = K.Q^T with the K rows in pi order (common.h): registers hold keys, the lane holds the query, so the
 // row max / sum are in-register reductions plus one lane <-> lane+32 exchange and the exponentiated tile is
 // directly the B operand of O^T += V^T.P^T (same scheme as kernels_attn.hip).
+template <int WS>  // window side known at compile time (7 for Swin-T), or 0 = read it from the geometry
 __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict__ qkv, int ld, bf16 *__restrict__ ctx,
                                                          int ldc, const float *__restrict__ bias_perm, WinGeom g,
                                                          int total, float scale2) {
@@ -278,7 +280,8 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
     unsigned char *Rg = (unsigned char *)(Vs + 32 * 128);
     const int head = id % g.heads, wlin = (id / g.heads) % g.nW, b = id / (g.heads * g.nW);
     const int wy = wlin / g.nWx, wx = wlin - wy * g.nWx;
-    const int A = g.ws * g.ws, C = g.heads * 32;
+    const int ws = WS ? WS : g.ws;
+    const int A = ws * ws, C = g.heads * 32;
     const bf16 *base = qkv + head * 32;
 
     // All global loads of the wave are issued in one burst (K / V rows of the window's tokens, the Q fragments of
@@ -291,14 +294,14 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) kreg[i][e] = vreg[i][e] = (bf16)0.f;
         if (key < A) {
-            const bf16 *row = base + win_token(g, b, wy, wx, key) * (size_t)ld + ch * 8;
+            const bf16 *row = base + win_token(g, ws, b, wy, wx, key) * (size_t)ld + ch * 8;
             kreg[i] = *(const bf16x8 *)(row + C);
             vreg[i] = *(const bf16x8 *)(row + 2 * C);
         }
     }
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        qtok[qt] = win_token(g, b, wy, wx, min(qt * 32 + r, A - 1));
+        qtok[qt] = win_token(g, ws, b, wy, wx, min(qt * 32 + r, A - 1));
 #pragma unroll
         for (int s = 0; s < 2; ++s) qf[qt][s] = *(const bf16x8 *)(base + qtok[qt] * (size_t)ld + 16 * s + 8 * h);
     }
@@ -312,8 +315,8 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
             *(bf16 *)(Vs + lds_off(d, key >> 3) + (key & 7) * 2) = vreg[i][e];
         }
     }
-    const bool masked = g.shift > 0 && (wy == g.H / g.ws - 1 || wx == g.nWx - 1);  // wave-uniform
-    if (masked) Rg[lane] = (unsigned char)(lane < A ? win_region(g, wy, wx, lane) : 0);
+    const bool masked = g.shift > 0 && (wy == g.H / ws - 1 || wx == g.nWx - 1);  // wave-uniform
+    if (masked) Rg[lane] = (unsigned char)(lane < A ? win_region(g, ws, wy, wx, lane) : 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 
@@ -424,18 +427,19 @@ __global__ __launch_bounds__(256) void swin_wattn_f32_kernel(const float *__rest
     float *Ks = smem + wave * (2 * 49 * 32), *Vs = Ks + 49 * 32;
     const int head = id % g.heads, wlin = (id / g.heads) % g.nW, b = id / (g.heads * g.nW);
     const int wy = wlin / g.nWx, wx = wlin - wy * g.nWx;
-    const int A = g.ws * g.ws, C = g.heads * 32;
+    const int ws = g.ws;
+    const int A = ws * ws, C = g.heads * 32;
     const float *base = qkv + head * 32;
     for (int idx = lane; idx < A * 8; idx += 64) {
         const int key = idx >> 3, ch = idx & 7;
-        const float *row = base + win_token(g, b, wy, wx, key) * (size_t)ld + ch * 4;
+        const float *row = base + win_token(g, ws, b, wy, wx, key) * (size_t)ld + ch * 4;
         *(f32x4 *)(Ks + key * 32 + ch * 4) = *(const f32x4 *)(row + C);
         *(f32x4 *)(Vs + key * 32 + ch * 4) = *(const f32x4 *)(row + 2 * C);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
     if (lane >= A) return;
-    const size_t qtok = win_token(g, b, wy, wx, lane);
+    const size_t qtok = win_token(g, ws, b, wy, wx, lane);
     float q[32];
 #pragma unroll
     for (int d = 0; d < 32; d += 4) {
@@ -443,7 +447,7 @@ __global__ __launch_bounds__(256) void swin_wattn_f32_kernel(const float *__rest
         q[d] = t[0]; q[d + 1] = t[1]; q[d + 2] = t[2]; q[d + 3] = t[3];
     }
     const bool masked = g.shift > 0;
-    const int myreg = masked ? win_region(g, wy, wx, lane) : 0;
+    const int myreg = masked ? win_region(g, ws, wy, wx, lane) : 0;
     const float *brow = bias_dense + ((size_t)head * A + lane) * A;
     float sc[49];
     float mx = -INFINITY;
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(256) void swin_wattn_f32_kernel(const float *__rest
 #pragma unroll
             for (int d = 0; d < 32; ++d) d0 = fmaf(q[d], Ks[j * 32 + d], d0);
             s = d0 * scale + brow[j];
-            if (masked && win_region(g, wy, wx, j) != myreg) s += -100.0f;
+            if (masked && win_region(g, ws, wy, wx, j) != myreg) s += -100.0f;
         }
         sc[j] = s;
         mx = fmaxf(mx, s);
@@ -490,9 +494,12 @@ hipError_t launch_swin_window_attention(int prec, const void *qkv, int ld, void 
     if (prec)
         swin_wattn_f32_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const float *)qkv, ld, (float *)ctx, ldc, bias_dense, g,
                                                                   (int)total, scale);
+    else if (ws == 7)
+        swin_wattn_kernel<7><<<dim3(blocks), dim3(256), 0, s>>>((const bf16 *)qkv, ld, (bf16 *)ctx, ldc, bias_perm, g,
+                                                                 (int)total, scale * 1.4426950408889634f);
     else
-        swin_wattn_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const bf16 *)qkv, ld, (bf16 *)ctx, ldc, bias_perm, g,
-                                                              (int)total, scale * 1.4426950408889634f);
+        swin_wattn_kernel<0><<<dim3(blocks), dim3(256), 0, s>>>((const bf16 *)qkv, ld, (bf16 *)ctx, ldc, bias_perm, g,
+                                                                 (int)total, scale * 1.4426950408889634f);
     return hipGetLastError();
 }
 
