@@ -113,25 +113,5 @@ __device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
     return r - g;
 }
 
-// The same GELU for bf16 outputs: erf(z) = z P(z^2) on |z| <= 3 (degree-8 minimax fit, |error| <= 2.5e-5 in fp32
-// Horner form; beyond +-3 the argument is clamped, error <= 2.2e-5) — no reciprocal, no exponential, all packed
-// FMAs: half the issue slots of gelu_erf2. Its error is two orders below the bf16 rounding of the result, so it is
-// used only where the activation leaves as bf16 (OCM_PREC_BF16); the fp32 path keeps gelu_erf2.
-__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
-    f32x2 z = x * 0.70710678118654752f;
-    z = f32x2{fminf(fmaxf(z[0], -3.0f), 3.0f), fminf(fmaxf(z[1], -3.0f), 3.0f)};
-    const f32x2 u = z * z;
-    f32x2 p = u * 4.077635651e-08f + (-1.946892553e-06f);
-    p = p * u + 4.110780719e-05f;
-    p = p * u + (-5.115864333e-04f);
-    p = p * u + 4.238998983e-03f;
-    p = p * u + (-2.511601150e-02f);
-    p = p * u + 1.111054420e-01f;
-    p = p * u + (-3.753391802e-01f);
-    p = p * u + 1.128275752e+00f;
-    const f32x2 hx = x * 0.5f;
-    return hx * (p * z) + hx;
-}
-
 // GELU(approximate='none') of the reference (nn.GELU, dino/vision_transformer.py:53)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }

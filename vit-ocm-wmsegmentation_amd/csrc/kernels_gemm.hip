@@ -74,11 +74,11 @@ struct EpiLinear {
                 if (MODE == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
-                        const f32x2 a = sizeof(OE) == 2 ? gelu_poly2(f32x2{v0[e], v0[e + 1]}) : gelu_erf2(f32x2{v0[e], v0[e + 1]});
+                        const f32x2 a = gelu_erf2(f32x2{v0[e], v0[e + 1]});
                         v0[e] = a[0];
                         v0[e + 1] = a[1];
                         if (W == 8) {
-                            const f32x2 b = gelu_poly2(f32x2{v1[e], v1[e + 1]});  // W == 8 <=> bf16 output
+                            const f32x2 b = gelu_erf2(f32x2{v1[e], v1[e + 1]});
                             v1[e] = b[0];
                             v1[e + 1] = b[1];
                         }
