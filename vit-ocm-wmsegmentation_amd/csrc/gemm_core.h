@@ -22,6 +22,18 @@
 #pragma once
 #include "common.h"
 
+// Development instrumentation (make stamps -> exp_libs/stamps.so, tools/stamps.py): thread 0 of every workgroup
+// records the shader clock at the phase boundaries of gemm_kernel. Compiled out unless -DOCM_GEMM_STAMPS.
+#ifdef OCM_GEMM_STAMPS
+__device__ unsigned long long g_stamps[8192 * 8];
+#define STAMP(i)                                                                                        \
+    do {                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define STAMP(i) ((void)0)
+#endif
+
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
@@ -269,7 +281,9 @@ __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::T
 #pragma unroll
                 for (int e = 0; e < 16; ++e) C[(row0 + acc_row32(e, h)) * COLS + col] = acc[i][j][e];
             }
+        STAMP(2);
         lds_barrier();
+        STAMP(3);
         epi.template run<PassCfg<Cfg::BM, Cfg::BN, Cfg::NT>>((const float *)C, m0, n0);
     } else if constexpr (!SWAP) {
         constexpr int PASS = Cfg::RB * Cfg::BN * 4;  // one band of RB rows
@@ -319,6 +333,13 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const E *__rest
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
+    STAMP(0);
     gemm_mainloop<Cfg, E, SWAP, KSTEPS>(al, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
-    run_epilogue<Cfg, SWAP>(acc, smem, epi, m0, n0);
+    STAMP(1);  // prologue + K loop done
+    run_epilogue<Cfg, SWAP>(acc, smem, epi, m0, n0);  // STAMP 2: accumulators staged, 3: barrier passed
+    STAMP(4);  // epilogue body issued
+#ifdef OCM_GEMM_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    STAMP(5);  // stores acknowledged
+#endif
 }

@@ -426,3 +426,10 @@ hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, cons
     if (prec) return launch_patch_e<float>(pa, (const float *)w, bias, pos, x, dim, s);
     return launch_patch_e<bf16>(pa, (const bf16 *)w, bias, pos, x, dim, s);
 }
+
+#ifdef OCM_GEMM_STAMPS
+// development only: copy the cycle stamps of the last GEMM launches to the host (tools/stamps.py)
+extern "C" int ocm_debug_stamps(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * 8);
+}
+#endif
