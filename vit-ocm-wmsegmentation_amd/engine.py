@@ -5,6 +5,7 @@ outputs and workspace, the current HIP stream, and `torch.distributed`. All arit
 of the hot path happens inside libocm_vit.so.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -50,7 +51,7 @@ class Engine:
         with torch.cuda.device(self.device):
             check(self.lib.ocm_vit_create(C.byref(self.cfg), C.byref(self._h)))
         self._ws = {}
-        self.hip_graph = False
+        self.hip_graph = {"1": True, "auto": "auto"}.get(os.environ.get("OCM_HIP_GRAPH", "0"), False)
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
