@@ -17,7 +17,6 @@ from functools import partial
 
 import torch
 import torch.nn as nn
-from torch.nn import functional as F
 
 from . import _lib
 from .dino.utils import trunc_normal_
@@ -118,62 +117,60 @@ def _conv1x1_pixel_shuffle(encoder, tokens, conv, stride, cache):
     return out
 
 
+def _pixel_shuffle_head(channels, stride, out_mult):
+    """Conv2d(channels, stride^2 * out_mult, 1) -> PixelShuffle(stride): the decoder head of model.py:60-66,147-152.
+    Kept as torch modules for their parameters / state_dict keys; the arithmetic runs in _conv1x1_pixel_shuffle."""
+    return nn.Sequential(nn.Conv2d(channels, stride * stride * out_mult, kernel_size=1), nn.PixelShuffle(stride))
+
+
+def _prefixed(encoder, method):
+    fn = getattr(encoder, method, None)
+    return {"encoder." + name for name in fn()} if fn is not None else {}
+
+
 class MIM(nn.Module):
+    """model.py:55-83: masked-image-modelling wrapper, forward(x, mask) -> (loss, x_rec, mask)."""
+
     def __init__(self, encoder, encoder_stride):
         super().__init__()
-        self.encoder = encoder
-        self.encoder_stride = encoder_stride
-        self.decoder = nn.Sequential(
-            nn.Conv2d(in_channels=self.encoder.num_features, out_channels=self.encoder_stride ** 2 * 3, kernel_size=1),
-            nn.PixelShuffle(self.encoder_stride),
-        )
-        self.in_chans = 3
-        self.patch_size = 8
+        self.encoder, self.encoder_stride = encoder, encoder_stride
+        self.decoder = _pixel_shuffle_head(encoder.num_features, encoder_stride, 3)
+        self.in_chans, self.patch_size = 3, 8
         self.__dict__["_dec_cache"] = {}
 
     @torch.no_grad()
     def forward(self, x, mask):
         _require_hip(x, "input")
-        tokens = self.encoder._encode(x, mask=mask.to(x.device), tokens=True)
+        mask = mask.to(x.device)
+        tokens = self.encoder._encode(x, mask=mask, tokens=True)
         x_rec = _conv1x1_pixel_shuffle(self.encoder, tokens, self.decoder[0], self.encoder_stride, self._dec_cache)
-        # the masked L1 loss (model.py:71-73) is training bookkeeping: a handful of elementwise torch ops
-        mask = mask.to(x.device).repeat_interleave(self.patch_size, 1).repeat_interleave(self.patch_size, 2).unsqueeze(1).contiguous()
-        loss_recon = F.l1_loss(x, x_rec, reduction='none')
-        loss = (loss_recon * mask).sum() / (mask.sum() + 1e-5) / self.in_chans
-        return loss, x_rec, mask
+        # masked L1 reconstruction loss (model.py:71-73) — training bookkeeping, a handful of elementwise torch ops
+        p = self.patch_size
+        pixel_mask = mask.repeat_interleave(p, 1).repeat_interleave(p, 2).unsqueeze(1).contiguous()
+        err = (x - x_rec).abs() * pixel_mask
+        loss = err.sum() / (pixel_mask.sum() + 1e-5) / self.in_chans
+        return loss, x_rec, pixel_mask
 
     @torch.jit.ignore
     def no_weight_decay(self):
-        if hasattr(self.encoder, 'no_weight_decay'):
-            return {'encoder.' + i for i in self.encoder.no_weight_decay()}
-        return {}
+        return _prefixed(self.encoder, "no_weight_decay")
 
     @torch.jit.ignore
     def no_weight_decay_keywords(self):
-        if hasattr(self.encoder, 'no_weight_decay_keywords'):
-            return {'encoder.' + i for i in self.encoder.no_weight_decay_keywords()}
-        return {}
+        return _prefixed(self.encoder, "no_weight_decay_keywords")
 
 
 class LinearProbing(nn.Module):
+    """model.py:142-174: encoder + segmentation decoder (layer_num 1: 1x1 conv + PixelShuffle; 2: two 3x3 convs)."""
+
     def __init__(self, encoder, encoder_stride, layer_num=1):
         super().__init__()
-        self.encoder = encoder
-        self.layer_num = layer_num
-        self.encoder_stride = encoder_stride
-        self.one_layer_decoder = nn.Sequential(
-            nn.Conv2d(in_channels=self.encoder.num_features, out_channels=self.encoder_stride ** 2, kernel_size=1),
-            nn.PixelShuffle(self.encoder_stride),
-        )
+        self.encoder, self.layer_num, self.encoder_stride = encoder, layer_num, encoder_stride
+        feats, s2 = encoder.num_features, encoder_stride ** 2
+        self.one_layer_decoder = _pixel_shuffle_head(feats, encoder_stride, 1)
         self.two_layer_decoder = nn.Sequential(
-            nn.Conv2d(in_channels=self.encoder.num_features, out_channels=self.encoder_stride ** 2 * 4, kernel_size=3,
-                      padding=1),
-            nn.BatchNorm2d(self.encoder_stride ** 2 * 4),
-            nn.ReLU(inplace=True),
-            nn.Conv2d(in_channels=self.encoder_stride ** 2 * 4, out_channels=self.encoder_stride ** 2, kernel_size=3,
-                      padding=1),
-            nn.PixelShuffle(self.encoder_stride),
-        )
+            nn.Conv2d(feats, 4 * s2, kernel_size=3, padding=1), nn.BatchNorm2d(4 * s2), nn.ReLU(inplace=True),
+            nn.Conv2d(4 * s2, s2, kernel_size=3, padding=1), nn.PixelShuffle(encoder_stride))
         self.__dict__["_dec_cache"] = {}
 
     @torch.no_grad()
