@@ -129,3 +129,23 @@ def test_swin_matches_transformers_fixture(dev, name, precision, tol):
     assert np.abs(out.pooler_output.cpu().numpy() - g["pooled"]).max() <= tol
     assert np.abs(out.last_hidden_state[:, :8, :64].cpu().numpy() - g["last_hidden_head"]).max() <= 4 * tol
     assert np.array_equal(out.logits.argmax(-1).cpu().numpy(), g["logits"].argmax(-1))
+
+
+@pytest.mark.gpu
+def test_swin_single_channel_batch_one_vs_oracle(dev):
+    """Edge geometry: one grayscale plane (num_channels = 1, K = 16 patch values) and a batch of one, against the
+    (transformers-pinned) oracle run on the same synthetic weights."""
+    cfg = dict(synth.SWIN_TINY, image_size=56, depths=(2, 2), num_heads=(3, 6), num_channels=1, num_labels=3)
+    sd = synth.synth_swin_state_dict(cfg, seed=31, qk_gain=4.0)
+    x = synth.synth_tiles(1, 56, seed=77, channels=1)
+    want = SO.swin_forward(sd, cfg, x)
+    hf = SW.SwinConfig(image_size=56, num_channels=1, depths=cfg["depths"], num_heads=cfg["num_heads"], num_labels=3)
+    model = SW.SwinForImageClassification(hf)
+    assert not model.load_state_dict(sd, strict=True).missing_keys
+    model = model.to(dev).eval().set_precision("fp32")
+    out = model(pixel_values=x.to(dev), output_hidden_states=True)
+    assert tuple(out.logits.shape) == (1, 3)
+    assert (out.logits.cpu() - want["logits"]).abs().max().item() <= 2e-4
+    assert (out.last_hidden_state.cpu() - want["last_hidden_state"]).abs().max().item() <= 1e-3
+    with pytest.raises(ValueError):
+        model(pixel_values=torch.zeros(1, 3, 56, 56, device=dev))
