@@ -317,16 +317,22 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     // a block that stops after its probabilities (get_last_selfattention) and returns no qkv never reads V
     void *vt_dst = (attn_only && !out_qkv) ? nullptr : w.vt;
     { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, vt_dst, out_qkv, batch, n, np, H, s)); }
-    if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s)); }
+    // selected query rows: a slice of the probabilities when those are materialised for this block anyway,
+    // else their own fp32 dot-product kernel (never the (H,N,N) matrix)
+    if (out_rows && !out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s)); }
     if (attn_only) {
         if (out_attn) {
             { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s)); }
             { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
+            if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
         }
         return OCM_OK;
     }
     { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s)); }
-    if (out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
+    if (out_attn) {
+        { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
+        if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
+    }
     // x = x + proj(ctx)
     { PROF(OCM_K_PROJ, s); HIP_TRY(launch_linear(pc, w.ctx, h->ptr<char>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s)); }
     // x = x + fc2(gelu(fc1(norm2(x))))

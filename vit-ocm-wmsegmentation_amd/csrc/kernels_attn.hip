@@ -701,6 +701,30 @@ __global__ __launch_bounds__(64) void attn_rows_kernel(const E *__restrict__ Q, 
     for (int key = 1 + lane; key < N; key += 64) dst[key - 1] = sc[key] * inv;
 }
 
+// When the full probabilities of the block are materialised anyway, the selected rows are a slice of them:
+// rows[bh][qi][j] = attn[bh][query[qi]][1 + j]  (bit-identical to the matrix the caller also receives).
+__global__ __launch_bounds__(256) void rows_from_probs_kernel(const float *__restrict__ attn,
+                                                              const int32_t *__restrict__ query_rows, int n_rows,
+                                                              float *__restrict__ rows, int N, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int j = (int)(i % (N - 1));
+        const size_t t = i / (N - 1);
+        const int qi = (int)(t % n_rows);
+        const size_t bh = t / n_rows;
+        const int query = query_rows ? query_rows[qi] : 0;
+        rows[i] = attn[(bh * N + query) * N + 1 + j];
+    }
+}
+
+hipError_t launch_rows_from_probs(const float *attn, const int32_t *query_rows, int n_rows, float *rows, int batch,
+                                  int n_tokens, int heads, hipStream_t s) {
+    const size_t total = (size_t)batch * heads * n_rows * (n_tokens - 1);
+    if (total == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    rows_from_probs_kernel<<<dim3(blocks), dim3(256), 0, s>>>(attn, query_rows, n_rows, rows, n_tokens, total);
+    return hipGetLastError();
+}
+
 hipError_t launch_attention_rows(int prec, const void *q, const void *k, const int32_t *query_rows, int n_rows,
                                  float *rows, int batch, int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
     if (n_rows <= 0) return hipSuccess;

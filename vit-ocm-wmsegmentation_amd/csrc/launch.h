@@ -36,6 +36,8 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
                             int n_tokens, int n_pad, int heads, float scale, hipStream_t s);
 hipError_t launch_attention_probs(int prec, const void *q, const void *k, const float *lse2, float *attn, int batch,
                                   int n_tokens, int n_pad, int heads, float scale, hipStream_t s);
+hipError_t launch_rows_from_probs(const float *attn, const int32_t *query_rows, int n_rows, float *rows, int batch,
+                                  int n_tokens, int heads, hipStream_t s);
 hipError_t launch_attention_rows(int prec, const void *q, const void *k, const int32_t *query_rows, int n_rows,
                                  float *rows, int batch, int n_tokens, int n_pad, int heads, float scale, hipStream_t s);
 hipError_t launch_attention_map(const float *attn, float *maps, int b, int heads, int n_tokens, int query, int hf,
