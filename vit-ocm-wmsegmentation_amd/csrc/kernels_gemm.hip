@@ -204,20 +204,27 @@ struct EpiQK {
     E *q, *k;
     float *qkv32;  // optional (3,B,H,N,64) fp32, or nullptr
     int M, ntok, npad, H, D, B;
-    // C is [BM][BN] (rows = tokens). One lane moves 8 consecutive head-dim columns of one token.
+    // C is [BM][BN] (rows = tokens). One lane moves 8 consecutive head-dim columns of one token. A lane keeps its
+    // column chunk for the whole tile and walks the rows in constant steps, so which / head / d are computed once
+    // and (image b, token t) advance incrementally: no integer division per chunk.
     template <class Cfg>
     __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, CPR = BN / 8;
+        static_assert(NT % CPR == 0 && BM % (NT / CPR) == 0, "a lane keeps one column chunk");
+        constexpr int RSTEP = NT / CPR, ITERS = BM / RSTEP;
+        const int col = (threadIdx.x % CPR) * 8, row0 = threadIdx.x / CPR;
+        const int n = n0 + col;
+        const int which = n / D, rem = n - which * D, head = rem >> 6, d = rem & 63;
+        int m = m0 + row0;
+        int b = m / ntok, t = m - b * ntok;
+        E *base = which ? k : q;
 #pragma unroll 4
-        for (int qd = threadIdx.x; qd < BM * CPR; qd += NT) {
-            const int row = qd / CPR, col = (qd - row * CPR) * 8;
-            const int m = m0 + row, n = n0 + col;
-            if (m >= M) continue;
-            const int which = n / D, rem = n - which * D, head = rem >> 6, d = rem & 63;
-            const int b = m / ntok, t = m - b * ntok;
+        for (int i = 0; i < ITERS; ++i) {
+            if (m >= M) break;
+            const int row = row0 + i * RSTEP;
             const f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
             const f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4);
-            E *dst = (which ? k : q) + ((int64_t)(b * H + head) * npad + t) * 64 + d;
+            E *dst = base + ((int64_t)(b * H + head) * npad + t) * 64 + d;
             if (sizeof(E) == 2) {
                 store_chunk(dst, v0, v1);
             } else {
@@ -228,6 +235,12 @@ struct EpiQK {
                 float *o = qkv32 + ((((int64_t)which * B + b) * H + head) * ntok + t) * 64 + d;
                 *(f32x4 *)o = v0;
                 *(f32x4 *)(o + 4) = v1;
+            }
+            m += RSTEP;
+            t += RSTEP;
+            while (t >= ntok) {
+                t -= ntok;
+                ++b;
             }
         }
     }
