@@ -99,8 +99,9 @@ def main():
     ap.add_argument("--arch", default="vit_small")
     ap.add_argument("--patch", type=int, default=16)
     ap.add_argument("--size", type=int, default=224)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"],
-                    help="operand precision of the contraction kernels (default: BASELINE.json's bf16)")
+    ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"],
+                    help="operand precision of the contraction kernels. Default: bf16x3 (split-bf16 on the bf16 MFMA), the "
+                         "fastest mode that holds the north star's 1e-3 on every golden weight set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-class table to stderr")
     args = ap.parse_args()
@@ -243,7 +244,9 @@ def main():
     value = tiles / dt
     dom_avg_s = dom_ms / max(dom_n, 1) * 1e-3
     achieved = cf[dom] / dom_avg_s / 1e12 if dom_n else None
-    peak = PEAK_BF16_DENSE_TFLOPS if args.precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_DENSE_TFLOPS
+    # MFMA instructions issued per algorithmic product: split-bf16 evaluates hi*hi + hi*lo + lo*hi
+    mfma_per_product = 3 if args.precision == "bf16x3" else 1
     line = {
         "metric": "OCM tiles/s (224x224, ViT-S/16 attention-map inference)" if (args.arch, p, S) == ("vit_small", 16, 224)
         else f"OCM tiles/s ({S}x{S}, {args.arch}/{p} attention-map inference)",
@@ -256,7 +259,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16" if args.precision == "bf16" else "f32",
+        "dtype": {"bf16": "bf16", "bf16x3": "bf16x3", "fp32": "f32"}[args.precision],
         "data": "synthetic",
         "config": {"workload": f"{args.arch} patch {p}, {B} tiles/GPU of {S}x{S} (RGB-replicated grayscale), "
                                f"get_last_selfattention -> (B,{H},{N},{N}) fp32 + CLS-row maps; random-init weights",
@@ -268,7 +271,8 @@ def main():
                      "peak": peak, "unit": "TFLOP/s",
                      "frac": round(achieved / peak, 4) if achieved else None,
                      "traffic": traffic, "launches": int(dom_n), "avg_launch_us": round(dom_avg_s * 1e6, 2),
-                     "flop_per_launch": cf[dom]},
+                     "flop_per_launch": cf[dom], "mfma_per_product": mfma_per_product,
+                     "mfma_pipe_frac": round(achieved * mfma_per_product / peak, 4) if achieved else None},
         "kernel_breakdown": breakdown,
     }
     if not args.no_cpu_baseline:

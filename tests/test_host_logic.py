@@ -38,7 +38,7 @@ def test_create_rejects_bad_configs(lib):
         return lib.ocm_vit_create(C.byref(cfg), C.byref(h))
 
     for bad in (dict(embed_dim=100), dict(num_heads=5), dict(patch_size=7), dict(in_chans=2), dict(depth=0),
-                dict(mlp_hidden=100), dict(precision=7), dict(precision=2)):
+                dict(mlp_hidden=100), dict(precision=7), dict(precision=3)):
         assert create(**bad) == _lib.OCM_EINVAL, bad
         assert lib.ocm_last_error()
     with pytest.raises(ValueError):

@@ -2,11 +2,14 @@
 (1) the golden vectors captured from the real reference and (2) the CPU oracle on the same seeded
 inputs. Needs a real MI355X.
 
-Tolerances
-  attention probabilities : 1e-3 absolute — the bar BASELINE.json's north_star states
+Tolerances (default precision = "bf16x3", split-bf16 operands)
+  attention probabilities : 1e-3 absolute — the bar BASELINE.json's north_star states — on EVERY golden weight
+                            set, the "peaked" one included (measured 1-2e-4 there, <= 1e-5 elsewhere)
   indices                 : bit-exact (token <-> patch mapping, nearest upsample, window origins)
-  feat / qkv / tokens     : bf16-operand GEMMs with fp32 accumulation and an fp32 residual stream;
-                            bounded relative to the tensor's own scale (stated per assert)
+  feat / qkv / tokens     : bounded relative to the tensor's own scale (stated per assert)
+The single-bf16 mode ("bf16", the fastest) is held to the same 1e-3 on the init / full / sharp sets; it is not
+claimed on the peaked set (rounding operands to 8 bits is amplified layer by layer to 4-8e-2 there, which is why
+it is not the default), and the fp32 mode to fp32 round-off.
 """
 import numpy as np
 import pytest
@@ -21,16 +24,10 @@ from vit_ocm_wmsegmentation_amd.sw_processing import SlidingWindowAttention
 pytestmark = pytest.mark.gpu
 
 ATTN_TOL = 1e-3
-# The "peaked" stress weights (qkv x8, attention max 0.79) sit in a regime where rounding the GEMM
-# operands to bf16 (8-bit mantissa) is amplified layer by layer: a CPU emulation that rounds exactly
-# the operands the bf16 kernels round reproduces L_inf ~6e-2 (and needs EVERY contraction, P.V
-# included, at ~fp32 precision to get under 1e-3). In OCM_PREC_BF16 that case is therefore held to
-# the emulated bound, not to 1e-3; the init / full / sharp sets are held to 1e-3.
-BF16_PEAKED_TOL = 1.5e-1
 
 
 def _attn_tol(name):
-    return BF16_PEAKED_TOL if "peaked" in name else ATTN_TOL
+    return ATTN_TOL
 
 
 def _rel(a, b):
@@ -66,19 +63,46 @@ def test_golden_parity(dev, name):
         am = a[:, :, 0, 1:].mean(1).argmax(-1).cpu().numpy()
         for b in range(B):
             assert hm_ref[b, am[b]] >= hm_ref[b].max() - 2 * tol
+        # split-bf16 operands (2^-17): round-off level on the well-conditioned sets, amplified on the peaked one
+        ftol = 2e-3 if "peaked" in name else 2e-4
+        assert _rel(feat[-1][:, :4, :16].cpu(), gold[pfx + "feat_head"]) < ftol
+        assert _rel(qkvs[-1][:, :, :, :3, :8].cpu(), gold[pfx + "qkv_head"]) < ftol
+        assert abs(float(feat[-1].double().abs().sum()) / float(gold[pfx + "feat_abssum"]) - 1) < 1e-4
+        tokens = model.prepare_tokens(x.to(dev))
+        assert _rel(tokens[:, :3, :16].cpu(), gold[pfx + "tokens_head"]) < 2e-5
+        assert abs(float(tokens.double().abs().sum()) / float(gold[pfx + "tokens_abssum"]) - 1) < 1e-5
+        if case.get("full"):
+            for j in range(n):
+                assert np.abs(attns[j].cpu().numpy() - gold[pfx + f"attn{j}"]).max() <= 1e-5
+                assert _rel(feat[j].cpu(), gold[pfx + f"feat{j}"]) < 2e-4
+                assert _rel(qkvs[j].cpu(), gold[pfx + f"qkv{j}"]) < 2e-4
+            assert _rel(tokens.cpu(), gold[pfx + "tokens"]) < 2e-5
+        assert torch.equal(model.get_last_selfattention(x.to(dev)), a)
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if "peaked" not in n])
+def test_golden_parity_bf16_mode(dev, name):
+    """OCM_PREC_BF16 (single bf16 operands, the fastest mode): 1e-3 on the init / full / sharp weight sets. The
+    peaked set is outside what this mode claims (module docstring) and is not run here."""
+    case, gold = CASES[name], load_golden(name)
+    model = build_module(case, dev).set_precision("bf16")
+    for idx, x in enumerate(case_inputs(case)):
+        pfx = f"in{idx}_"
+        n = case["n"]
+        feat, attns, qkvs = model.get_intermediate_feat(x.to(dev), n)
+        a = attns[-1]
+        N = a.shape[-1]
+        e_cls = np.abs(a[:, :, 0, 1:].cpu().numpy() - gold[pfx + "cls_rows"]).max()
+        e_mid = np.abs(a[:, :, N // 2, :].cpu().numpy() - gold[pfx + "mid_rows"]).max()
+        print(f"\n[bf16 {name}/{idx}] attn L_inf: cls-row {e_cls:.2e} mid-row {e_mid:.2e}")
+        assert e_cls <= ATTN_TOL and e_mid <= ATTN_TOL
+        assert float((a.sum(-1) - 1).abs().max()) < 1e-4
         # bf16 GEMM operands: a few 1e-3 of the tensor scale per layer, accumulated over the depth
         assert _rel(feat[-1][:, :4, :16].cpu(), gold[pfx + "feat_head"]) < 4e-2
         assert _rel(qkvs[-1][:, :, :, :3, :8].cpu(), gold[pfx + "qkv_head"]) < 4e-2
-        assert abs(float(feat[-1].double().abs().sum()) / float(gold[pfx + "feat_abssum"]) - 1) < 5e-3
         tokens = model.prepare_tokens(x.to(dev))
         assert _rel(tokens[:, :3, :16].cpu(), gold[pfx + "tokens_head"]) < 5e-3  # one bf16 GEMM, K <= 768
-        assert abs(float(tokens.double().abs().sum()) / float(gold[pfx + "tokens_abssum"]) - 1) < 1e-3
-        if case.get("full"):
-            for j in range(n):
-                assert np.abs(attns[j].cpu().numpy() - gold[pfx + f"attn{j}"]).max() <= ATTN_TOL
-                assert _rel(feat[j].cpu(), gold[pfx + f"feat{j}"]) < 3e-2
-                assert _rel(qkvs[j].cpu(), gold[pfx + f"qkv{j}"]) < 3e-2
-            assert _rel(tokens.cpu(), gold[pfx + "tokens"]) < 5e-3
+        assert torch.equal(model.get_last_selfattention(x.to(dev)), a)
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -119,7 +143,8 @@ def test_entry_points_agree_with_oracle(dev, name):
         e = float((attns[j].cpu() - oattn[j]).abs().max())
         print(f"\n[{name}] block -{2 - j}: attn L_inf {e:.2e} feat rel {_rel(feat[j].cpu(), ofeat[j]):.2e}")
         assert e <= _attn_tol(name)
-        assert _rel(feat[j].cpu(), ofeat[j]) < 6e-2 and _rel(qkvs[j].cpu(), oqkv[j]) < 6e-2
+        ftol = 2e-3 if "peaked" in name else 2e-4
+        assert _rel(feat[j].cpu(), ofeat[j]) < ftol and _rel(qkvs[j].cpu(), oqkv[j]) < ftol
     # get_last_selfattention == attns[-1] (bit-for-bit in the reference: SURVEY §0-3; here the same
     # kernels run on the same operands, so it is bit-exact too)
     last = model.get_last_selfattention(xg)

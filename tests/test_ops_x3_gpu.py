@@ -1,0 +1,144 @@
+"""Kernel-level parity of the OCM_PREC_BF16X3 operators (split-bf16 pairs, three bf16 MFMAs per product) against
+float64 references: a split operand carries ~17 bits, the dropped lo*lo term is 2^-18 relative, so results must sit at
+a few 1e-6 of the data scale — 250x inside what a single bf16 operand (2^-9) could reach. Runs on a real MI355X only."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from vit_ocm_wmsegmentation_amd import _lib
+from vit_ocm_wmsegmentation_amd.engine import from_split, to_operand
+
+pytestmark = pytest.mark.gpu
+X3 = _lib.OCM_PREC_BF16X3
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ok(lib, rc):
+    assert rc == 0, lib.ocm_last_error().decode()
+
+
+def _rand(shape, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dev)
+
+
+def test_split_roundtrip_and_layout(lib, dev):
+    x = _rand((37, 96), dev, 1, 3.0)
+    xs = to_operand(x, X3)
+    assert xs.dtype == torch.int32 and xs.shape == x.shape
+    back = from_split(xs)
+    assert ((back - x).abs() <= x.abs() * 2 ** -16).all()  # hi + lo carries >= 16 bits
+    # layout: every 32 elements are [32 x bf16 hi | 32 x bf16 lo]
+    raw = xs.view(torch.bfloat16).reshape(37, 3, 2, 32)
+    hi = x.to(torch.bfloat16).reshape(37, 3, 32)
+    assert torch.equal(raw[:, :, 0], hi)
+    lo = (x - hi.reshape(37, 96).float()).to(torch.bfloat16).reshape(37, 3, 32)
+    assert torch.equal(raw[:, :, 1], lo)
+    with pytest.raises(ValueError):
+        to_operand(x[:, :40], X3)
+
+
+@pytest.mark.parametrize("rows,dim", [(1000, 384), (7, 192), (513, 768), (65, 160)])
+def test_layernorm_split_out(lib, dev, rows, dim):
+    x = _rand((rows, dim), dev, 1, 3.0) + 0.5
+    g = _rand((dim,), dev, 2) * 0.1 + 1
+    b = _rand((dim,), dev, 3) * 0.1
+    ref = F.layer_norm(x.double(), (dim,), g.double(), b.double(), 1e-6)
+    ys = torch.empty((rows, dim), dtype=torch.int32, device=dev)
+    _ok(lib, lib.ocm_op_layernorm(_p(x), _p(g), _p(b), _p(ys), _lib.OCM_LN_SPLIT, rows, dim, 1e-6, _s()))
+    assert (from_split(ys).double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (12608, 1536, 384), (333, 384, 1536), (70, 96, 192),
+                                   (12608, 384, 384), (64, 192, 64)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+def test_linear_x3(lib, dev, M, N, K, epi):
+    a = _rand((M, K), dev, 40)
+    w = _rand((N, K), dev, 41, 0.05)
+    bias = _rand((N,), dev, 42, 0.1)
+    resid = _rand((M, N), dev, 43)
+    ref = a.double() @ w.double().t() + bias.double()
+    if epi == 1:
+        ref = ref + resid.double()
+    if epi == 2:
+        ref = F.gelu(ref)
+    act_out = epi in (2, 3)
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+    if act_out:
+        out = out.view(torch.int32)
+    if epi == 1:
+        out.copy_(resid)
+    _ok(lib, lib.ocm_op_linear(X3, _p(to_operand(a, X3)), _p(to_operand(w, X3)), _p(bias), _p(out) if epi == 1 else None,
+                               _p(out), M, N, K, epi, _s()))
+    got = from_split(out) if act_out else out
+    # operands carry 2^-17, fp32 accumulation over K terms of |a||w| ~ 0.05
+    assert (got.double() - ref).abs().max().item() < 3e-5 * max(1.0, math.sqrt(K) / 8)
+
+
+@pytest.mark.parametrize("B,N,H", [(3, 197, 6), (2, 17, 2), (1, 577, 12), (5, 50, 3)])
+def test_qkv_proj_x3(lib, dev, B, N, H):
+    D = H * 64
+    a, w, bias = _rand((B * N, D), dev, 50), _rand((3 * D, D), dev, 51, 0.05), _rand((3 * D,), dev, 52, 0.1)
+    npad = lib.ocm_n_pad_prec(X3, N)
+    assert npad % 32 == 0 and npad >= N
+    q = torch.zeros((B * H, npad, 64), dtype=torch.int32, device=dev)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((B * H, 64, npad), dtype=torch.int32, device=dev)
+    qkv32 = torch.empty((3, B, H, N, 64), device=dev)
+    _ok(lib, lib.ocm_op_qkv_proj(X3, _p(to_operand(a, X3)), _p(to_operand(w, X3)), _p(bias), _p(q), _p(k), _p(vt),
+                                 _p(qkv32), B, N, H, _s()))
+    ref = (a.double() @ w.double().t() + bias.double()).reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    tol = 3e-5 * max(1.0, math.sqrt(D) / 8)
+    assert (qkv32.double() - ref).abs().max().item() < tol
+    assert (from_split(q)[:, :N].double() - ref[0].reshape(B * H, N, 64)).abs().max().item() < tol
+    assert (from_split(k)[:, :N].double() - ref[1].reshape(B * H, N, 64)).abs().max().item() < tol
+    assert (from_split(vt)[:, :, :N].double() - ref[2].reshape(B * H, N, 64).transpose(1, 2)).abs().max().item() < tol
+    assert (q[:, N:] == 0).all()  # padding rows are never written
+    # V^T padding columns share 128-byte groups with valid keys but are never written either
+    assert (from_split(vt)[:, :, N:] == 0).all()
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (1, 17, 2), (1, 577, 3), (1, 64, 1), (1, 65, 1), (1, 2305, 2)])
+@pytest.mark.parametrize("sharp", [1.0, 3.0])
+def test_attention_x3(lib, dev, B, N, H, sharp):
+    g = torch.Generator().manual_seed(60)
+    q = (torch.randn((B * H, N, 64), generator=g) * sharp).to(dev)
+    k = (torch.randn((B * H, N, 64), generator=g) * sharp).to(dev)
+    v = torch.randn((B * H, N, 64), generator=g).to(dev)
+    npad = lib.ocm_n_pad_prec(X3, N)
+    nan = float("nan")  # padding may hold anything, NaN included
+    qp = torch.full((B * H, npad, 64), nan, device=dev)
+    kp = torch.full((B * H, npad, 64), nan, device=dev)
+    vp = torch.full((B * H, 64, npad), nan, device=dev)
+    qp[:, :N], kp[:, :N], vp[:, :, :N] = q, k, v.transpose(1, 2)
+    qs, ks, vs = to_operand(qp, X3), to_operand(kp, X3), to_operand(vp, X3)
+    scale = 0.125
+    s = (q.double() @ k.double().transpose(1, 2)) * scale
+    pref = s.softmax(-1)
+    oref = (pref @ v.double()).reshape(B, H, N, 64).permute(0, 2, 1, 3).reshape(B, N, H * 64)
+    ctx = torch.full((B, N, H * 64), nan, device=dev).view(torch.int32)
+    lse = torch.empty((B * H, N), device=dev)
+    _ok(lib, lib.ocm_op_attention(X3, _p(qs), _p(ks), _p(vs), _p(ctx), _p(lse), B, N, H, scale, _s()))
+    assert (lse.double() - torch.logsumexp(s, -1) / math.log(2.0)).abs().max().item() < 2e-4
+    assert (from_split(ctx).double() - oref).abs().max().item() < 5e-5
+    attn = torch.full((B, H, N, N), nan, device=dev)
+    _ok(lib, lib.ocm_op_attention_probs(X3, _p(qs), _p(ks), _p(lse), _p(attn), B, N, H, scale, _s()))
+    assert (attn.reshape(B * H, N, N).double() - pref).abs().max().item() < 3e-5
+    assert (attn.sum(-1) - 1).abs().max().item() < 1e-4
+    lse2 = torch.empty_like(lse)
+    _ok(lib, lib.ocm_op_attention(X3, _p(qs), _p(ks), _p(vs), None, _p(lse2), B, N, H, scale, _s()))
+    assert torch.equal(lse, lse2)
+    rows_idx = torch.tensor([0, N - 1, N // 2], dtype=torch.int32, device=dev)
+    rows = torch.empty((B, H, 3, N - 1), device=dev)
+    _ok(lib, lib.ocm_op_attention_rows(X3, _p(qs), _p(ks), _p(rows_idx), 3, _p(rows), B, N, H, scale, _s()))
+    assert (rows.double() - pref.reshape(B, H, N, N)[:, :, rows_idx.long(), 1:]).abs().max().item() < 3e-5

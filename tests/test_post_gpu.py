@@ -87,9 +87,10 @@ def test_segment_pipeline_vs_oracle(dev):
         rows.append(attn[0, :, 0, 1:].numpy())
     ref_small = O.tile_postprocess(np.stack(rows)).reshape(9, 12, 12)
     ref_heat = O.concat_crops(O.bilinear_upsample(ref_small, 8), stride, window)
-    # min-max normalisation divides by the (small) dynamic range of near-uniform maps, amplifying the bf16 error
-    # of the attention (random-init maps span ~1e-3): compare on the 0..255 scale within 3 grey levels (bf16 mode)
-    assert np.abs(out["heat"].cpu().numpy() - ref_heat).max() < 3.0
+    # min-max normalisation divides by the (small) dynamic range of near-uniform maps (random-init maps span
+    # ~1e-3), amplifying the forward's error: on the 0..255 scale the default split-bf16 mode stays within a tenth
+    # of a grey level (single bf16: within 3 grey levels)
+    assert np.abs(out["heat"].cpu().numpy() - ref_heat).max() < 0.1
     rimg, rmask, rlevel = O.heatmap_mask(out["heat"].cpu().numpy())  # same heat -> identical mask
     assert out["level"] == rlevel and np.array_equal(out["mask"].cpu().numpy(), rmask)
     # fp32 mode: the heat map itself agrees to round-off
@@ -148,7 +149,7 @@ def test_threshold_rejects_cpu_and_save(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16"])
 def test_segment_images_matches_oracle_chain(dev, precision):
     """eval.py:126-171 (method ours / otsu / heatmap_threshold) for a batch of tiles against the oracle chain
     run image by image on the CPU, as the reference's loop does."""
@@ -165,7 +166,7 @@ def test_segment_images_matches_oracle_chain(dev, precision):
     attn = O.get_last_selfattention(sd, cfg, x).numpy()
     hf = wf = S // p
     maps = average_attention_maps(model, x.to(dev)).cpu().numpy()
-    tol = 2e-6 if precision == "fp32" else 2e-4
+    tol = {"fp32": 2e-6, "bf16x3": 4e-6, "bf16": 2e-4}[precision]
     for method, k in (("ours", 0), ("otsu", 1), ("heatmap_threshold", 2)):
         masks, _ = segment_images(model, x.to(dev), method=method, as_numpy=True)
         for b in range(B):
@@ -174,9 +175,9 @@ def test_segment_images_matches_oracle_chain(dev, precision):
             want = O.threshold_masks(O.to_pil_gray_u8(x[b].numpy()), want_map)[0][k]
             # uint8 truncation and the Otsu level quantise the map: allow a sliver of boundary pixels to flip
             frac = np.mean(masks[b] != want)
-            # pixels whose value sits within the map's error of the Otsu level flip: a sliver in fp32 mode; in bf16
-            # mode the 2e-4 map error is a few percent of the dynamic range of these near-uniform synthetic maps
-            # (measured: 3.2 % of the pixels)
-            assert frac <= (0.0 if k == 1 else (2e-3 if precision == "fp32" else 6e-2)), (method, b, frac)
+            # pixels whose value sits within the map's error of the Otsu level flip: a sliver in the fp32 and the
+            # default split-bf16 modes; in single-bf16 mode the 2e-4 map error is a few percent of the dynamic range
+            # of these near-uniform synthetic maps (measured: 3.2 % of the pixels)
+            assert frac <= (0.0 if k == 1 else (6e-2 if precision == "bf16" else 2e-3)), (method, b, frac)
     with pytest.raises(ValueError):
         segment_images(model, x.to(dev), method="k-means")

@@ -10,12 +10,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OCM_VIT_LIB lets kernel experiments A/B two builds of the same ABI; the default is the in-tree build.
 LIB_PATH = os.environ.get("OCM_VIT_LIB") or os.path.join(_HERE, "libocm_vit.so")
 
-OCM_ABI_VERSION = 3
+OCM_ABI_VERSION = 4
 OCM_OK, OCM_EINVAL, OCM_ESTATE, OCM_EHIP, OCM_ENOMEM, OCM_ENAME = 0, 1, 2, 3, 4, 5
 
 OCM_PREC_BF16 = 0
 OCM_PREC_FP32 = 1
-PRECISIONS = {"bf16": OCM_PREC_BF16, "fp32": OCM_PREC_FP32}
+OCM_PREC_BF16X3 = 2
+PRECISIONS = {"bf16": OCM_PREC_BF16, "fp32": OCM_PREC_FP32, "bf16x3": OCM_PREC_BF16X3}
+DEFAULT_PRECISION = "bf16x3"  # the mode that holds the north star's 1e-3 on every golden weight set
+OCM_LN_F32, OCM_LN_BF16, OCM_LN_SPLIT = 0, 1, 2
 
 OCM_OUT_FEAT = 1 << 0
 OCM_OUT_ATTN = 1 << 1
@@ -113,6 +116,9 @@ SIGNATURES = {
     "ocm_vit_final_norm": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "ocm_op_layernorm": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _vp]),
     "ocm_op_cast_bf16": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "ocm_op_cast_split": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "ocm_op_merge_split": (C.c_int, [_vp, _vp, _sz, _vp]),
+    "ocm_n_pad_prec": (_i32, [_i32, _i32]),
     "ocm_op_linear": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ocm_n_pad": (_i32, [_i32]),
     "ocm_op_qkv_proj": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),

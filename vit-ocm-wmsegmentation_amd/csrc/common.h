@@ -52,6 +52,46 @@ __device__ __forceinline__ bf16x8 cvt8(f32x4 lo, f32x4 hi) {
     return r;
 }
 
+// ---- split-bf16 pairs (OCM_PREC_BF16X3) -------------------------------------------------------------
+// A value x is carried as two bf16 numbers hi = bf16(x), lo = bf16(x - hi): x = hi + lo up to 2^-17 |x|, and a
+// product is evaluated as hi*hi' + hi*lo' + lo*hi' on the bf16 MFMA (three instructions, fp32 accumulate; the
+// dropped lo*lo' term is 2^-18 relative). Memory / LDS layout of such a tensor: the contraction axis is cut into
+// groups of 32 elements and each group is one 128-byte row segment [32 x hi | 32 x lo] — the same bytes per
+// element as fp32, every 16-byte chunk is a ready MFMA fragment, and a 128-byte LDS row is one K step of 32.
+struct sp32 {  // element tag: sizeof == 4 bytes per logical element
+    uint32_t bits;
+};
+// byte offset of the hi half of element `col` inside its row (lo half: + 64)
+__device__ __host__ __forceinline__ int sp_off(int col) { return (col >> 5) * 128 + (col & 31) * 2; }
+__device__ __forceinline__ void split1(float x, bf16 &hi, bf16 &lo) {
+    hi = (bf16)x;
+    lo = (bf16)(x - (float)hi);
+}
+__device__ __forceinline__ void split4(const f32x4 &x, bf16x4 &hi, bf16x4 &lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bf16 t = (bf16)x[e];
+        hi[e] = t;
+        lo[e] = (bf16)(x[e] - (float)t);
+    }
+}
+__device__ __forceinline__ void split8(const f32x4 &a, const f32x4 &b, bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const bf16 t = (bf16)a[e], u = (bf16)b[e];
+        hi[e] = t;
+        lo[e] = (bf16)(a[e] - (float)t);
+        hi[4 + e] = u;
+        lo[4 + e] = (bf16)(b[e] - (float)u);
+    }
+}
+// acc += a*b for split operands: small terms first
+__device__ __forceinline__ f32x16 mfma32x3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+}
+
 // Bijective XCD-aware remap of a linear workgroup id: consecutive logical ids
 // (which share an A row panel) land on one XCD / one L2. Speed only.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -93,6 +93,7 @@ extern "C" int ocm_prof_end(double *ms_per_class, int64_t *launches_per_class) {
 extern "C" int ocm_abi_version(void) { return OCM_ABI_VERSION; }
 extern "C" const char *ocm_last_error(void) { return g_err.c_str(); }
 extern "C" int32_t ocm_n_pad(int32_t n_tokens) { return ocm_round_up(n_tokens, 8); }
+extern "C" int32_t ocm_n_pad_prec(int32_t precision, int32_t n_tokens) { return ocm_n_pad_for(precision, n_tokens); }
 
 // ------------------------------------------------------------------------------------------
 // parameter store
@@ -114,7 +115,7 @@ struct BlockP {
 struct ocm_vit {
     ocm_vit_config cfg;
     int D, H, L, M, p, C, Kpe;
-    int prec;  // 0 = bf16 operands, 1 = fp32 operands (element size esz of matrices / activations)
+    int prec;  // 0 = bf16 operands, 1 = fp32 operands, 2 = split-bf16 pairs (element size esz of matrices / activations)
     size_t esz;
     std::vector<Param> params;
     std::vector<BlockP> blk;
@@ -153,12 +154,12 @@ extern "C" int ocm_vit_create(const ocm_vit_config *cfg, ocm_vit_t **out) {
     if (cfg->mlp_hidden <= 0 || cfg->mlp_hidden % 64)
         return fail(OCM_EINVAL, "mlp_hidden %d must be a multiple of 64", cfg->mlp_hidden);
     if (cfg->depth <= 0) return fail(OCM_EINVAL, "depth %d must be positive", cfg->depth);
-    if (cfg->precision != OCM_PREC_BF16 && cfg->precision != OCM_PREC_FP32)
-        return fail(OCM_EINVAL, "precision %d is not one of OCM_PREC_BF16 / OCM_PREC_FP32", cfg->precision);
+    if (cfg->precision != OCM_PREC_BF16 && cfg->precision != OCM_PREC_FP32 && cfg->precision != OCM_PREC_BF16X3)
+        return fail(OCM_EINVAL, "precision %d is not one of OCM_PREC_BF16 / OCM_PREC_FP32 / OCM_PREC_BF16X3", cfg->precision);
     ocm_vit *h = new ocm_vit();
     h->cfg = *cfg;
     h->D = D; h->H = H; h->L = cfg->depth; h->M = cfg->mlp_hidden; h->p = p; h->C = C; h->Kpe = C * p * p;
-    h->prec = cfg->precision == OCM_PREC_FP32 ? 1 : 0;
+    h->prec = cfg->precision;  // OCM_PREC_* values are the kernels' `prec` selector
     h->esz = h->prec ? 4 : 2;
     h->arena = nullptr;
     h->arena_bytes = 0;
@@ -217,7 +218,9 @@ extern "C" int ocm_vit_set_param(ocm_vit_t *h, const char *name, const float *de
             HIP_TRY(hipMemcpyAsync(dst, dev_src, count * 4, hipMemcpyDeviceToDevice, s));
         } else if (pr.kind == P_BF16) {  // matrix: bf16 copy, or fp32 copy in OCM_PREC_FP32
             if (count != pr.count) return fail(OCM_EINVAL, "%s: expected %zu elements, got %zu", name, pr.count, count);
-            if (h->prec)
+            if (h->prec == 2)
+                HIP_TRY(launch_cast_split(dev_src, dst, count, s));
+            else if (h->prec)
                 HIP_TRY(hipMemcpyAsync(dst, dev_src, count * 4, hipMemcpyDeviceToDevice, s));
             else
                 HIP_TRY(launch_cast_bf16(dev_src, (bf16 *)dst, count, s));
@@ -226,12 +229,16 @@ extern "C" int ocm_vit_set_param(ocm_vit_t *h, const char *name, const float *de
             if (count == 0 || count % per) return fail(OCM_EINVAL, "%s: %zu elements is not (D=%d, C, %d, %d)", name, count, h->D, h->p, h->p);
             const int cref = (int)(count / per);
             if (cref == h->C) {
-                if (h->prec)
+                if (h->prec == 2)
+                    HIP_TRY(launch_cast_split(dev_src, dst, count, s));
+                else if (h->prec)
                     HIP_TRY(hipMemcpyAsync(dst, dev_src, count * 4, hipMemcpyDeviceToDevice, s));
                 else
                     HIP_TRY(launch_cast_bf16(dev_src, (bf16 *)dst, count, s));
             } else if (h->C == 1) {  // grayscale fold: W_eff = W.sum(dim=1)
-                if (h->prec)
+                if (h->prec == 2)
+                    HIP_TRY(launch_fold_split(dev_src, dst, h->D, cref, (int)pp, s));
+                else if (h->prec)
                     HIP_TRY(launch_fold_f32(dev_src, (float *)dst, h->D, cref, (int)pp, s));
                 else
                     HIP_TRY(launch_fold_cast_bf16(dev_src, (bf16 *)dst, h->D, cref, (int)pp, s));
@@ -274,7 +281,7 @@ static Workspace carve(const ocm_vit *h, int batch, int n, char *base) {
         off += (bytes + 255) & ~(size_t)255;
         return pch;
     };
-    const size_t T = (size_t)batch * n, BH = (size_t)batch * h->H, np = ocm_n_pad(n);
+    const size_t T = (size_t)batch * n, BH = (size_t)batch * h->H, np = ocm_n_pad_for(h->prec, n);
     const size_t e = h->esz;
     w.x = (float *)take(T * h->D * 4);
     w.xn = take(T * h->D * e);
@@ -309,11 +316,11 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
                      float *out_attn, float *out_qkv, const int32_t *query_rows, int n_rows, float *out_rows,
                      hipStream_t s) {
     const BlockP &bp = h->blk[i];
-    const int D = h->D, H = h->H, T = batch * n, np = ocm_n_pad(n);
+    const int D = h->D, H = h->H, T = batch * n, np = ocm_n_pad_for(h->prec, n);
     const float eps = h->cfg.ln_eps, scale = h->cfg.qk_scale;
-    const int pc = h->prec;
+    const int pc = h->prec, lnk = ln_kind_of_prec(pc);
     // y = attn(norm1(x))
-    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, !pc, T, D, eps, s)); }
+    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, lnk, T, D, eps, s)); }
     // a block that stops after its probabilities (get_last_selfattention) and returns no qkv never reads V
     void *vt_dst = (attn_only && !out_qkv) ? nullptr : w.vt;
     { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, vt_dst, out_qkv, batch, n, np, H, s)); }
@@ -336,7 +343,7 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     // x = x + proj(ctx)
     { PROF(OCM_K_PROJ, s); HIP_TRY(launch_linear(pc, w.ctx, h->ptr<char>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s)); }
     // x = x + fc2(gelu(fc1(norm2(x))))
-    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln2_g), h->ptr<float>(bp.ln2_b), w.xn, !pc, T, D, eps, s)); }
+    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln2_g), h->ptr<float>(bp.ln2_b), w.xn, lnk, T, D, eps, s)); }
     { PROF(OCM_K_FC1, s); HIP_TRY(launch_linear(pc, w.xn, h->ptr<char>(bp.fc1_w), h->ptr<float>(bp.fc1_b), nullptr, w.hid, T, h->M, D, OCM_EPI_BIAS_GELU_BF16, s)); }
     { PROF(OCM_K_FC2, s); HIP_TRY(launch_linear(pc, w.hid, h->ptr<char>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s)); }
     return OCM_OK;
@@ -399,7 +406,7 @@ extern "C" int ocm_vit_final_norm(ocm_vit_t *h, const float *x, float *y, int64_
     if (!h || !x || !y) return fail(OCM_EINVAL, "null argument");
     int rc = ocm_vit_params_ready(h);
     if (rc) return rc;
-    HIP_TRY(launch_layernorm(x, h->ptr<float>(h->norm_g), h->ptr<float>(h->norm_b), y, false, rows, h->D, h->cfg.ln_eps,
+    HIP_TRY(launch_layernorm(x, h->ptr<float>(h->norm_g), h->ptr<float>(h->norm_b), y, 0, rows, h->D, h->cfg.ln_eps,
                              (hipStream_t)stream));
     return OCM_OK;
 }
@@ -423,14 +430,14 @@ static int enqueue_forward(ocm_vit *h, const ocm_vit_io *io, int n, hipStream_t 
         if (ret && (fl & OCM_OUT_FEAT)) {
             PROF(OCM_K_LN, s);
             HIP_TRY(launch_layernorm(w.x, h->ptr<float>(h->norm_g), h->ptr<float>(h->norm_b),
-                                     io->out_feat + (size_t)slot * T * h->D, false, T, h->D, h->cfg.ln_eps, s));
+                                     io->out_feat + (size_t)slot * T * h->D, 0, T, h->D, h->cfg.ln_eps, s));
         }
     }
     if (fl & OCM_OUT_TOKENS)
         HIP_TRY(hipMemcpyAsync(io->out_tokens, w.x, T * h->D * 4, hipMemcpyDeviceToDevice, s));
     if (fl & OCM_OUT_FMAP) {  // norm(x)[:, 1:] -> (B, D, hp, wp); the hidden-activation buffer is free by now
         float *yn = (float *)w.hid;
-        HIP_TRY(launch_layernorm(w.x, h->ptr<float>(h->norm_g), h->ptr<float>(h->norm_b), yn, false, T, h->D,
+        HIP_TRY(launch_layernorm(w.x, h->ptr<float>(h->norm_g), h->ptr<float>(h->norm_b), yn, 0, T, h->D,
                                  h->cfg.ln_eps, s));
         HIP_TRY(launch_tokens_to_fmap(yn, io->out_fmap, B, n, h->D, s));
     }
@@ -532,11 +539,27 @@ extern "C" int ocm_vit_graph_stats(const ocm_vit_t *h, uint64_t *replays, uint64
 // ------------------------------------------------------------------------------------------
 // stand-alone operators
 // ------------------------------------------------------------------------------------------
-extern "C" int ocm_op_layernorm(const float *x, const float *gamma, const float *beta, void *y, int32_t out_bf16,
+extern "C" int ocm_op_layernorm(const float *x, const float *gamma, const float *beta, void *y, int32_t out_kind,
                                 int64_t rows, int32_t dim, float eps, void *stream) {
     if (!x || !gamma || !beta || !y) return fail(OCM_EINVAL, "null argument");
     if (dim <= 0 || dim % 2 || dim > 1024) return fail(OCM_EINVAL, "dim %d must be even and <= 1024", dim);
-    HIP_TRY(launch_layernorm(x, gamma, beta, y, out_bf16 != 0, rows, dim, eps, (hipStream_t)stream));
+    if (out_kind < 0 || out_kind > 2) return fail(OCM_EINVAL, "out_kind %d is not one of OCM_LN_F32 / _BF16 / _SPLIT", out_kind);
+    if (out_kind == OCM_LN_SPLIT && dim % 32) return fail(OCM_EINVAL, "split-pair output needs dim %% 32 == 0 (got %d)", dim);
+    HIP_TRY(launch_layernorm(x, gamma, beta, y, out_kind, rows, dim, eps, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_cast_split(const float *src, void *dst, size_t count, void *stream) {
+    if (!src || !dst) return fail(OCM_EINVAL, "null argument");
+    if (count % 32) return fail(OCM_EINVAL, "split-pair tensors hold multiples of 32 elements (got %zu)", count);
+    HIP_TRY(launch_cast_split(src, dst, count, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_merge_split(const void *src, float *dst, size_t count, void *stream) {
+    if (!src || !dst) return fail(OCM_EINVAL, "null argument");
+    if (count % 32) return fail(OCM_EINVAL, "split-pair tensors hold multiples of 32 elements (got %zu)", count);
+    HIP_TRY(launch_merge_split(src, dst, count, (hipStream_t)stream));
     return OCM_OK;
 }
 
@@ -547,8 +570,9 @@ extern "C" int ocm_op_cast_bf16(const float *src, void *dst, size_t count, void 
 }
 
 static int prec_of(int32_t precision, int *pc) {
-    if (precision != OCM_PREC_BF16 && precision != OCM_PREC_FP32) return fail(OCM_EINVAL, "bad precision %d", precision);
-    *pc = precision == OCM_PREC_FP32;
+    if (precision != OCM_PREC_BF16 && precision != OCM_PREC_FP32 && precision != OCM_PREC_BF16X3)
+        return fail(OCM_EINVAL, "bad precision %d", precision);
+    *pc = precision;
     return OCM_OK;
 }
 
@@ -558,6 +582,8 @@ extern "C" int ocm_op_linear(int32_t precision, const void *a, const void *w, co
     if (rc) return rc;
     if (!a || !w || !out) return fail(OCM_EINVAL, "null argument");
     if (M <= 0 || N <= 0 || N % 32 || K <= 0 || K % 64) return fail(OCM_EINVAL, "bad shape M=%d N=%d K=%d (N%%32, K%%64)", M, N, K);
+    if (pc == 2 && (epilogue == OCM_EPI_BIAS_GELU_BF16 || epilogue == OCM_EPI_BIAS_BF16) && N % 32)
+        return fail(OCM_EINVAL, "split-pair outputs need N %% 32 == 0");
     if (epilogue < 0 || epilogue > 3) return fail(OCM_EINVAL, "bad epilogue %d", epilogue);
     if (epilogue == OCM_EPI_BIAS_RESID_F32 && !resid) return fail(OCM_EINVAL, "residual epilogue without resid");
     HIP_TRY(launch_linear(pc, a, w, bias, resid, out, M, N, K, epilogue, (hipStream_t)stream));
@@ -570,7 +596,7 @@ extern "C" int ocm_op_qkv_proj(int32_t precision, const void *a, const void *w, 
     if (rc) return rc;
     if (!a || !w || !bias || !q || !k || !vt) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_qkv(pc, a, w, bias, q, k, vt, qkv_f32, batch, n_tokens, ocm_n_pad(n_tokens), heads, (hipStream_t)stream));
+    HIP_TRY(launch_qkv(pc, a, w, bias, q, k, vt, qkv_f32, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, (hipStream_t)stream));
     return OCM_OK;
 }
 
@@ -581,7 +607,7 @@ extern "C" int ocm_op_attention(int32_t precision, const void *q, const void *k,
     if (!q || !k || !vt) return fail(OCM_EINVAL, "null argument");
     if (!ctx && !lse2) return fail(OCM_EINVAL, "nothing to compute: ctx and lse2 are both null");
     if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_attention(pc, q, k, vt, ctx, lse2, batch, n_tokens, ocm_n_pad(n_tokens), heads, scale,
+    HIP_TRY(launch_attention(pc, q, k, vt, ctx, lse2, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, scale,
                              (hipStream_t)stream));
     return OCM_OK;
 }
@@ -592,7 +618,7 @@ extern "C" int ocm_op_attention_probs(int32_t precision, const void *q, const vo
     if (rc) return rc;
     if (!q || !k || !lse2 || !attn) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_attention_probs(pc, q, k, lse2, attn, batch, n_tokens, ocm_n_pad(n_tokens), heads, scale,
+    HIP_TRY(launch_attention_probs(pc, q, k, lse2, attn, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, scale,
                                    (hipStream_t)stream));
     return OCM_OK;
 }
@@ -604,7 +630,7 @@ extern "C" int ocm_op_attention_rows(int32_t precision, const void *q, const voi
     if (rc) return rc;
     if (!q || !k || !rows) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || n_tokens <= 1 || heads <= 0 || n_rows <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_attention_rows(pc, q, k, query_rows, n_rows, rows, batch, n_tokens, ocm_n_pad(n_tokens), heads, scale,
+    HIP_TRY(launch_attention_rows(pc, q, k, query_rows, n_rows, rows, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, scale,
                                   (hipStream_t)stream));
     return OCM_OK;
 }

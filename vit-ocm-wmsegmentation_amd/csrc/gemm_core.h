@@ -49,6 +49,7 @@ struct GemmCfg {
     static constexpr int RB = 32 * WAVES_M, CB = 32 * WAVES_N;
     static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
     static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging must divide evenly");
+    static_assert(NT % 8 == 0, "a thread keeps one chunk column");
 };
 
 // what an epilogue sees of one staged pass: a PBM x PBN fp32 image handled by NT threads
@@ -57,30 +58,38 @@ struct PassCfg {
     static constexpr int BM = PBM, BN = PBN, NT = NT_;
 };
 
-// operand element traits: a 16-byte chunk holds EPC elements, an LDS row (one K step) KROW elements
+// operand element traits: an LDS row (one K step, 128 bytes) holds KROW elements; an epilogue lane writes EPW
+// consecutive elements of an activation row. MODE: 0 = bf16, 1 = fp32, 2 = split-bf16 pairs (common.h: sp32).
+// In every mode K step t of a row is the 128 bytes at byte offset t * 128 of that row, as eight 16-byte chunks.
 template <class E>
 struct Elem;
 template <>
 struct Elem<bf16> {
     typedef bf16x8 Chunk;
-    static constexpr int EPC = 8, KROW = 64;
+    static constexpr int MODE = 0, KROW = 64, EPW = 8;
 };
 template <>
 struct Elem<float> {
     typedef f32x4 Chunk;
-    static constexpr int EPC = 4, KROW = 32;
+    static constexpr int MODE = 1, KROW = 32, EPW = 4;
+};
+template <>
+struct Elem<sp32> {
+    typedef f32x4 Chunk;  // 16 opaque bytes: 8 hi or 8 lo halves
+    static constexpr int MODE = 2, KROW = 32, EPW = 8;
 };
 
-// A operand = row-major activations of element type E.
+// A operand = row-major activations of element type E (lda in elements).
 template <class E>
 struct RowLoader {
     const E *A;
     int64_t lda;
-    typedef const E *Handle;
+    typedef const char *Handle;
     typedef typename Elem<E>::Chunk Raw;
-    __device__ __forceinline__ Handle row(int m) const { return A + (int64_t)m * lda; }
-    __device__ __forceinline__ Raw load(Handle h, int k) const { return *(const Raw *)(h + k); }
-    __device__ __forceinline__ static Raw finish(const Raw &r) { return r; }
+    __device__ __forceinline__ Handle row(int m) const { return (const char *)A + (int64_t)m * lda * (int)sizeof(E); }
+    // chunk c of K step t
+    __device__ __forceinline__ Raw load(Handle h, int t, int c) const { return *(const Raw *)(h + t * 128 + c * 16); }
+    __device__ __forceinline__ static Raw finish(const Raw &r, int) { return r; }
 };
 
 // One K step of MFMAs on the LDS tiles at Ab / Bb (already offset to the wave's rows).
@@ -88,7 +97,29 @@ template <class Cfg, class E, bool SWAP>
 __device__ __forceinline__ void mma_step(const char *Ab, const char *Bb, int r, int h,
                                          f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
-    if constexpr (sizeof(E) == 2) {
+    if constexpr (Elem<E>::MODE == 2) {
+        // split-bf16: the 128-byte row is [hi k 0..31 | lo k 0..31]; two k16 sub-steps, three MFMAs per product
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = *(const bf16x8 *)(Ab + i * Cfg::RB * 128 + lds_off(r, 2 * s + h));
+                al[i] = *(const bf16x8 *)(Ab + i * Cfg::RB * 128 + lds_off(r, 4 + 2 * s + h));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = *(const bf16x8 *)(Bb + j * Cfg::CB * 128 + lds_off(r, 2 * s + h));
+                bl[j] = *(const bf16x8 *)(Bb + j * Cfg::CB * 128 + lds_off(r, 4 + 2 * s + h));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = SWAP ? mfma32x3(bh[j], bl[j], ah[i], al[i], acc[i][j])
+                                     : mfma32x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+        }
+    } else if constexpr (Elem<E>::MODE == 0) {
         // rows (i*WAVES_M + wm)*32 + r: the swizzle term (row>>1)&7 only depends on r because the tile row
         // offsets are multiples of 32. Lane (r, h) holds k = 16s + 8h .. +7 of row r.
 #pragma unroll
@@ -135,7 +166,7 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
                                               int M, int N, int K, char *smem, f32x16 (&acc)[Cfg::TM][Cfg::TN],
                                               const float *__restrict__ bias) {
     typedef typename Elem<E>::Chunk Chunk;
-    constexpr int EPC = Elem<E>::EPC, KROW = Elem<E>::KROW;
+    constexpr int KROW = Elem<E>::KROW;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
     constexpr int A_CH = Cfg::A_CH, B_CH = Cfg::B_CH, TM = Cfg::TM, TN = Cfg::TN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,36 +175,36 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
     char *As = smem;
     char *Bs = smem + 2 * BM * 128;
 
+    // NT % 8 == 0: a thread keeps chunk column cc = tid & 7 for all of its chunks
+    const int cc = tid & 7;
     typename ALoad::Handle a_h[A_CH];
-    const E *b_h[B_CH];
-    int a_off[A_CH], b_off[B_CH], a_k[A_CH], b_k[B_CH];
+    const char *b_h[B_CH];
+    int a_off[A_CH], b_off[B_CH];
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-        const int q = tid + NT * i, row = q >> 3, c = q & 7;
+        const int q = tid + NT * i, row = q >> 3;
         a_h[i] = al.row(min(m0 + row, M - 1));
-        a_off[i] = lds_off(row, c);
-        a_k[i] = c * EPC;
+        a_off[i] = lds_off(row, cc);
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
-        const int q = tid + NT * i, row = q >> 3, c = q & 7;
-        b_h[i] = W + (int64_t)min(n0 + row, N - 1) * ldw;
-        b_off[i] = lds_off(row, c);
-        b_k[i] = c * EPC;
+        const int q = tid + NT * i, row = q >> 3;
+        b_h[i] = (const char *)W + (int64_t)min(n0 + row, N - 1) * ldw * (int)sizeof(E) + cc * 16;
+        b_off[i] = lds_off(row, cc);
     }
     struct Slot {
         typename ALoad::Raw a[A_CH];
         Chunk b[B_CH];
     };
-    auto issue = [&](Slot &sl, int k0) {
+    auto issue = [&](Slot &sl, int t) {  // K step t
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) sl.a[i] = al.load(a_h[i], k0 + a_k[i]);
+        for (int i = 0; i < A_CH; ++i) sl.a[i] = al.load(a_h[i], t, cc);
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) sl.b[i] = *(const Chunk *)(b_h[i] + k0 + b_k[i]);
+        for (int i = 0; i < B_CH; ++i) sl.b[i] = *(const Chunk *)(b_h[i] + t * 128);
     };
     auto commit = [&](int buf, const Slot &sl) {
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i) *(Chunk *)(As + buf * BM * 128 + a_off[i]) = ALoad::finish(sl.a[i]);
+        for (int i = 0; i < A_CH; ++i) *(Chunk *)(As + buf * BM * 128 + a_off[i]) = ALoad::finish(sl.a[i], cc);
 #pragma unroll
         for (int i = 0; i < B_CH; ++i) *(Chunk *)(Bs + buf * BN * 128 + b_off[i]) = sl.b[i];
     };
@@ -207,7 +238,7 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
         // in step t-2 (L2 latency under load is ~1 us, more than one step). The stream is unconditional (indices
         // past the end re-read the last tile into a dead slot) and the loop is fully unrolled with a constant
         // trip count, so hipcc counts its own `s_waitcnt vmcnt(N)` instead of draining to 0.
-        auto issue2 = [&](Slot &sl, int t) { issue(sl, min(t, KSTEPS - 1) * KROW); };
+        auto issue2 = [&](Slot &sl, int t) { issue(sl, min(t, KSTEPS - 1)); };
         Slot s0, s1;
         issue2(s0, 0);
         issue2(s1, 1);
@@ -248,7 +279,7 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
         lds_barrier();
         for (int t = 0; t < nt; ++t) {
             const int buf = t & 1;
-            if (t + 1 < nt) issue(s0, (t + 1) * KROW);
+            if (t + 1 < nt) issue(s0, t + 1);
             compute(buf);
             if (t + 1 < nt) commit(buf ^ 1, s0);
             lds_barrier();

@@ -609,6 +609,239 @@ __global__ __launch_bounds__(256) void attn_probs_f32_kernel(const float *__rest
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// OCM_PREC_BF16X3: the flash kernel on split-bf16 pairs (common.h: sp32). q / k rows are 256 bytes
+// [hi d 0..31 | lo d 0..31 | hi d 32..63 | lo d 32..63]; V^T rows are key-contiguous in the same 128-byte groups of
+// 32 keys. Every product runs as three bf16 MFMAs (hi*hi + hi*lo + lo*hi), P is split in registers. An LDS tile of
+// 64 keys is two images (one per 128-byte group) of [64 rows][128 B] with the usual chunk swizzle, so the
+// fragment reads are the conflict-free pattern of the bf16 kernel and staging is a byte copy.
+template <bool WANT_O>
+__global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const char *__restrict__ Q, const char *__restrict__ Kk,
+                                                             const char *__restrict__ Vt, char *__restrict__ ctx,
+                                                             float *__restrict__ lse2, int N, int npad, int H,
+                                                             float scale2) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 16384];  // K[2] | Vt[2], 16 KiB each
+    char *Ks = smem, *Vs = smem + 2 * 16384;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int qblk, bh;
+    xcd_remap2(qblk, bh);
+    const int q0 = (qblk * 4 + wave) * 32;
+    const bool active = q0 < N;  // wave-uniform
+    const char *Qb = Q + (int64_t)bh * npad * 256;
+    const char *Kb = Kk + (int64_t)bh * npad * 256;
+    const char *Vb = Vt + (int64_t)bh * 64 * npad * 4;
+
+    // Q^T as the B operand: lane (query r, half h) holds Q[q0+r][16s + 8h .. +7], hi and lo halves
+    bf16x8 qh[4], ql[4];
+    {
+        const char *qp = Qb + (int64_t)min(q0 + r, N - 1) * 256;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const char *p = qp + (s >> 1) * 128 + ((s & 1) * 16 + 8 * h) * 2;
+            qh[s] = *(const bf16x8 *)p;
+            ql[s] = *(const bf16x8 *)(p + 64);
+        }
+    }
+
+    // staging: 1024 K chunks + 1024 V^T chunks of 16 B per tile, 256 threads -> 4 + 4 each
+    f32x4 rk[4], rv[4];
+    auto issue = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qd = tid + 256 * i, row = qd >> 4, c16 = qd & 15;  // row: key (K) or d (V^T); 16 chunks per row
+            const int key = min(kt * 64 + row, N - 1);
+            rk[i] = *(const f32x4 *)(Kb + (int64_t)key * 256 + c16 * 16);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            const int key0 = kt * 64 + (c16 >> 3) * 32 + (c16 & 3) * 8;  // first of the chunk's 8 keys (hi or lo halves)
+            if (WANT_O && key0 < N) {  // key0 < N <= npad: the chunk lies inside the row
+                v = *(const f32x4 *)(Vb + (int64_t)row * npad * 4 + (kt * 2 + (c16 >> 3)) * 128 + (c16 & 7) * 16);
+                if (key0 + 8 > N) {  // keys >= N are padding: force exact zeros (0 * garbage must not be NaN)
+                    bf16x8 t = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (key0 + e >= N) t[e] = (bf16)0.f;
+                    v = __builtin_bit_cast(f32x4, t);
+                }
+            }
+            rv[i] = v;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int qd = tid + 256 * i, row = qd >> 4, c16 = qd & 15;
+            const int o = buf * 16384 + (c16 >> 3) * 8192 + lds_off(row, c16 & 7);
+            *(f32x4 *)(Ks + o) = rk[i];
+            *(f32x4 *)(Vs + o) = rv[i];
+        }
+    };
+
+    f32x16 O[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[0][e] = O[1][e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int pr = pi_row(r);
+    const int ntiles = (N + 63) >> 6;
+
+    issue(0);
+    commit(0);
+    lds_barrier();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ntiles) issue(kt + 1);
+        if (active) {
+            const char *Kt = Ks + buf * 16384, *Vtile = Vs + buf * 16384;
+            f32x16 S[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) S[sub][e] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const char *kp = Kt + (s >> 1) * 8192 + sub * 32 * 128;
+                    const bf16x8 kh = *(const bf16x8 *)(kp + lds_off(pr, (s & 1) * 2 + h));
+                    const bf16x8 kl = *(const bf16x8 *)(kp + lds_off(pr, 4 + (s & 1) * 2 + h));
+                    S[sub] = mfma32x3(kh, kl, qh[s], ql[s], S[sub]);
+                }
+            }
+            if ((kt + 1) * 64 > N) {  // tail tile: padding keys -> -inf (wave-uniform branch)
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        if (kt * 64 + sub * 32 + key_of_reg(e, h) >= N) S[sub][e] = -INFINITY;
+            }
+            float mx = fmaxf(S[0][0], S[1][0]);
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(S[0][e], S[1][e]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx * scale2);  // finite: every tile holds at least one valid key
+            const float alpha = fast_exp2(m - mn);
+            m = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float p = fast_exp2(fmaf(S[sub][e], scale2, -mn));
+                    S[sub][e] = p;
+                    ps += p;
+                }
+            l = fmaf(l, alpha, ps);
+            if (WANT_O) {
+                if (__any(alpha != 1.0f)) {  // the running max moved somewhere in this wave
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        O[0][e] *= alpha;
+                        O[1][e] *= alpha;
+                    }
+                }
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        bf16x8 ph, pl;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float pv = S[sub][8 * s2 + e];
+                            const bf16 t = (bf16)pv;
+                            ph[e] = t;
+                            pl[e] = (bf16)(pv - (float)t);
+                        }
+#pragma unroll
+                        for (int db = 0; db < 2; ++db) {
+                            const char *vp = Vtile + sub * 8192 + db * 32 * 128;
+                            const bf16x8 vh = *(const bf16x8 *)(vp + lds_off(r, 2 * s2 + h));
+                            const bf16x8 vl = *(const bf16x8 *)(vp + lds_off(r, 4 + 2 * s2 + h));
+                            O[db] = mfma32x3(vh, vl, ph, pl, O[db]);
+                        }
+                    }
+            }
+        }
+        if (kt + 1 < ntiles) commit(buf ^ 1);
+        lds_barrier();
+    }
+
+    if (!active) return;
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const int qrow = q0 + r;
+    if (qrow < N) {
+        if (lse2 && h == 0) lse2[(int64_t)bh * N + qrow] = m + __log2f(lt);
+        if (WANT_O) {
+            const float inv = 1.0f / lt;
+            const int b = bh / H, head = bh - b * H;
+            char *dst = ctx + ((int64_t)b * N + qrow) * (H * 64) * 4 + head * 256;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = O[db][4 * g + e] * inv;
+                    bf16x4 oh, ol;
+                    split4(o, oh, ol);
+                    char *p = dst + db * 128 + (8 * g + 4 * h) * 2;
+                    *(bf16x4 *)p = oh;
+                    *(bf16x4 *)(p + 64) = ol;
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_probs_x3_kernel(const char *__restrict__ Q, const char *__restrict__ Kk,
+                                                            const float *__restrict__ lse2, float *__restrict__ attn,
+                                                            int N, int npad, float scale2) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    int qblk, bh;
+    xcd_remap2(qblk, bh);
+    const int q0 = (qblk * 4 + wave) * 32;
+    if (q0 >= N) return;  // no barriers in this kernel
+    const char *Qb = Q + (int64_t)bh * npad * 256;
+    const char *Kb = Kk + (int64_t)bh * npad * 256;
+    auto loadrow = [&](const char *base, int row, bf16x8(&hi)[4], bf16x8(&lo)[4]) {
+        const char *rp = base + (int64_t)row * 256;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const char *p = rp + (s >> 1) * 128 + ((s & 1) * 16 + 8 * h) * 2;
+            hi[s] = *(const bf16x8 *)p;
+            lo[s] = *(const bf16x8 *)(p + 64);
+        }
+    };
+    bf16x8 qh[4], ql[4];
+    loadrow(Qb, min(q0 + r, N - 1), qh, ql);
+    float lr[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lr[e] = lse2[(int64_t)bh * N + min(q0 + acc_row32(e, h), N - 1)];
+    float *out = attn + (int64_t)bh * N * N;
+    const int ktiles = (N + 31) >> 5;
+    bf16x8 kh[4], kl[4], nh[4], nl[4];
+    loadrow(Kb, min(r, N - 1), kh, kl);
+    for (int kt = 0; kt < ktiles; ++kt) {
+        if (kt + 1 < ktiles) loadrow(Kb, min((kt + 1) * 32 + r, N - 1), nh, nl);
+        f32x16 S;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) S = mfma32x3(qh[s], ql[s], kh[s], kl[s], S);  // rows = queries, col (lane) = key
+        const int key = kt * 32 + r;
+        if (key < N) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qrow = q0 + acc_row32(e, h);
+                if (qrow < N) out[(int64_t)qrow * N + key] = fast_exp2(S[e] * scale2 - lr[e]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kh[s] = nh[s];
+            kl[s] = nl[s];
+        }
+    }
+}
+
 hipError_t launch_attention(int prec, const void *q, const void *k, const void *vt, void *ctx, float *lse2, int batch,
                             int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
     if (!prec)
@@ -616,6 +849,16 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
                                      n_tokens, n_pad, heads, scale, s);
     const int qtiles = (n_tokens + 31) / 32;
     const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
+    if (prec == 2) {
+        if (n_pad % 32) return hipErrorInvalidValue;
+        if (ctx)
+            attn_fwd_x3_kernel<true><<<grid, block, 0, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx,
+                                                            lse2, n_tokens, n_pad, heads, scale * LOG2E);
+        else
+            attn_fwd_x3_kernel<false><<<grid, block, 0, s>>>((const char *)q, (const char *)k, (const char *)vt,
+                                                             (char *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+        return hipGetLastError();
+    }
     if (ctx)
         attn_fwd_f32_kernel<true><<<grid, block, 0, s>>>((const float *)q, (const float *)k, (const float *)vt,
                                                          (float *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
@@ -629,7 +872,10 @@ hipError_t launch_attention_probs(int prec, const void *q, const void *k, const 
                                   int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
     const int qtiles = (n_tokens + 31) / 32;
     const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
-    if (prec)
+    if (prec == 2)
+        attn_probs_x3_kernel<<<grid, block, 0, s>>>((const char *)q, (const char *)k, lse2, attn, n_tokens, n_pad,
+                                                    scale * LOG2E);
+    else if (prec)
         attn_probs_f32_kernel<<<grid, block, 0, s>>>((const float *)q, (const float *)k, lse2, attn, n_tokens, n_pad,
                                                      scale * LOG2E);
     else
@@ -640,18 +886,25 @@ hipError_t launch_attention_probs(int prec, const void *q, const void *k, const 
 
 // ------------------------------------------------------------------------------------------
 // rows[b][h][i][j-1] = softmax_j(q[query_i] . k[j] * scale), j = 1..N-1   (utils.py:232)
-__device__ __forceinline__ void load8(const bf16 *p, float (&o)[8]) {
-    const bf16x8 t = *(const bf16x8 *)p;
+// elements 8c .. 8c+7 of a 64-element head row as fp32
+__device__ __forceinline__ void load8(const bf16 *rowp, int c, float (&o)[8]) {
+    const bf16x8 t = *(const bf16x8 *)(rowp + c * 8);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (float)t[e];
 }
-__device__ __forceinline__ void load8(const float *p, float (&o)[8]) {
-    const f32x4 a = *(const f32x4 *)p, b = *(const f32x4 *)(p + 4);
+__device__ __forceinline__ void load8(const float *rowp, int c, float (&o)[8]) {
+    const f32x4 a = *(const f32x4 *)(rowp + c * 8), b = *(const f32x4 *)(rowp + c * 8 + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         o[e] = a[e];
         o[4 + e] = b[e];
     }
+}
+__device__ __forceinline__ void load8(const sp32 *rowp, int c, float (&o)[8]) {  // hi + lo
+    const char *p = (const char *)rowp + sp_off(c * 8);
+    const bf16x8 hi = *(const bf16x8 *)p, lo = *(const bf16x8 *)(p + 64);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)hi[e] + (float)lo[e];
 }
 
 template <class E>
@@ -667,7 +920,7 @@ __global__ __launch_bounds__(64) void attn_rows_kernel(const E *__restrict__ Q, 
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float t[8];
-        load8(qp + c * 8, t);
+        load8(qp, c, t);
 #pragma unroll
         for (int e = 0; e < 8; ++e) qv[c * 8 + e] = t[e];
     }
@@ -678,7 +931,7 @@ __global__ __launch_bounds__(64) void attn_rows_kernel(const E *__restrict__ Q, 
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             float t[8];
-            load8(kp + c * 8, t);
+            load8(kp, c, t);
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc = fmaf(qv[c * 8 + e], t[e], acc);
         }
@@ -730,7 +983,10 @@ hipError_t launch_attention_rows(int prec, const void *q, const void *k, const i
     if (n_rows <= 0) return hipSuccess;
     const dim3 grid(n_rows, batch * heads), block(64);
     const size_t lds = (size_t)n_tokens * sizeof(float);
-    if (prec)
+    if (prec == 2)
+        attn_rows_kernel<sp32><<<grid, block, lds, s>>>((const sp32 *)q, (const sp32 *)k, query_rows, n_rows, rows,
+                                                        n_tokens, n_pad, scale * LOG2E);
+    else if (prec)
         attn_rows_kernel<float><<<grid, block, lds, s>>>((const float *)q, (const float *)k, query_rows, n_rows, rows,
                                                          n_tokens, n_pad, scale * LOG2E);
     else

@@ -24,9 +24,29 @@ static inline bool big_tiles_pay(int M, int N, int K) {
     return K >= 768 && N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) >= 512;
 }
 
-// 16-byte store of 16/sizeof(OE) consecutive outputs taken from fp32 values
-__device__ __forceinline__ void store_chunk(bf16 *dst, const f32x4 &v0, const f32x4 &v1) { *(bf16x8 *)dst = cvt8(v0, v1); }
-__device__ __forceinline__ void store_chunk(float *dst, const f32x4 &v0, const f32x4 &) { *(f32x4 *)dst = v0; }
+// Store Elem<OE>::EPW consecutive activations (taken from fp32 values) at element column `col` of the row that
+// starts at `rowp`: 8 bf16 (16 B), 4 fp32 (16 B) or 8 split pairs (16 B of hi halves + 16 B of lo halves).
+__device__ __forceinline__ void store_act(bf16 *, char *rowp, int col, const f32x4 &v0, const f32x4 &v1) {
+    *(bf16x8 *)(rowp + col * 2) = cvt8(v0, v1);
+}
+__device__ __forceinline__ void store_act(float *, char *rowp, int col, const f32x4 &v0, const f32x4 &) {
+    *(f32x4 *)(rowp + col * 4) = v0;
+}
+__device__ __forceinline__ void store_act(sp32 *, char *rowp, int col, const f32x4 &v0, const f32x4 &v1) {
+    bf16x8 hi, lo;
+    split8(v0, v1, hi, lo);
+    *(bf16x8 *)(rowp + sp_off(col)) = hi;
+    *(bf16x8 *)(rowp + sp_off(col) + 64) = lo;
+}
+// one element
+__device__ __forceinline__ void store_act1(bf16 *, char *rowp, int col, float v) { *(bf16 *)(rowp + col * 2) = (bf16)v; }
+__device__ __forceinline__ void store_act1(float *, char *rowp, int col, float v) { *(float *)(rowp + col * 4) = v; }
+__device__ __forceinline__ void store_act1(sp32 *, char *rowp, int col, float v) {
+    bf16 hi, lo;
+    split1(v, hi, lo);
+    *(bf16 *)(rowp + sp_off(col)) = hi;
+    *(bf16 *)(rowp + sp_off(col) + 64) = lo;
+}
 
 // ------------------------------------------------------------------------------------------
 // nn.Linear epilogues
@@ -47,7 +67,7 @@ struct EpiLinear {
     __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
         constexpr bool ACT_OUT = (MODE == 2 || MODE == 3);
-        constexpr int W = ACT_OUT ? 16 / (int)sizeof(OE) : 4;  // columns per lane
+        constexpr int W = ACT_OUT ? Elem<OE>::EPW : 4;  // columns per lane
         constexpr int CPR = BN / W;                            // chunks per row
         constexpr int TOTAL = BM * CPR, ITERS = (TOTAL + NT - 1) / NT;
         f32x4 rs[MODE == 1 ? ITERS : 1];
@@ -84,7 +104,7 @@ struct EpiLinear {
                         }
                     }
                 }
-                store_chunk((OE *)out + o, v0, v1);
+                store_act((OE *)nullptr, (char *)out + (int64_t)m * ldo * (int)sizeof(OE), n, v0, v1);
             }
         }
     }
@@ -131,7 +151,7 @@ static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, 
                                      int N, int K, hipStream_t s) {
     RowLoader<E> al{a, K};
     EpiLinear<MODE, E> epi{bias, resid, out, M, N, N};
-    if constexpr (sizeof(E) == 2)
+    if constexpr (Elem<E>::MODE == 0)
         if (big_tiles_pay(M, N, K)) return launch_gemm<Cfg256x256, E, false>(al, w, K, M, N, K, epi, s);
     // Tile choice: fill >= 2 workgroups per CU (256 CUs) when the problem allows it.
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
@@ -178,6 +198,7 @@ static hipError_t launch_linear_ld_e(const E *a, int64_t lda, const E *w, const 
 
 hipError_t launch_linear_ld(int prec, const void *a, int64_t lda, const void *w, const float *bias, const float *resid,
                             void *out, int64_t ldo, int M, int N, int K, int epilogue, hipStream_t s) {
+    if (prec == 2) return hipErrorInvalidValue;  // the strided launcher serves Swin (bf16 / fp32 only)
     if (prec)
         return launch_linear_ld_e<float>((const float *)a, lda, (const float *)w, bias, resid, out, ldo, M, N, K, epilogue,
                                          s);
@@ -186,6 +207,7 @@ hipError_t launch_linear_ld(int prec, const void *a, int64_t lda, const void *w,
 
 hipError_t launch_linear(int prec, const void *a, const void *w, const float *bias, const float *resid, void *out, int M,
                          int N, int K, int epilogue, hipStream_t s) {
+    if (prec == 2) return launch_linear_e<sp32>((const sp32 *)a, (const sp32 *)w, bias, resid, out, M, N, K, epilogue, s);
     if (prec) return launch_linear_e<float>((const float *)a, (const float *)w, bias, resid, out, M, N, K, epilogue, s);
     return launch_linear_e<bf16>((const bf16 *)a, (const bf16 *)w, bias, resid, out, M, N, K, epilogue, s);
 }
@@ -224,12 +246,12 @@ struct EpiQK {
             const int row = row0 + i * RSTEP;
             const f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
             const f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4);
-            E *dst = base + ((int64_t)(b * H + head) * npad + t) * 64 + d;
-            if (sizeof(E) == 2) {
-                store_chunk(dst, v0, v1);
+            char *rowp = (char *)base + ((int64_t)(b * H + head) * npad + t) * 64 * (int)sizeof(E);
+            if (Elem<E>::EPW == 8) {
+                store_act((E *)nullptr, rowp, d, v0, v1);
             } else {
-                store_chunk(dst, v0, v0);
-                store_chunk(dst + 4, v1, v1);
+                store_act((E *)nullptr, rowp, d, v0, v0);
+                store_act((E *)nullptr, rowp, d + 4, v1, v1);
             }
             if (qkv32) {
                 float *o = qkv32 + ((((int64_t)which * B + b) * H + head) * ntok + t) * 64 + d;
@@ -269,7 +291,7 @@ struct EpiVt {
         for (int row = threadIdx.x / BM; row < BN; row += RS) {
             const int rem = rem0 + row, head = rem >> 6, d = rem & 63;
             const float v = C[row * BM + col];
-            vt[((int64_t)(b * H + head) * 64 + d) * npad + t] = (E)v;
+            store_act1((E *)nullptr, (char *)vt + ((int64_t)(b * H + head) * 64 + d) * npad * (int)sizeof(E), t, v);
             if (qkv32) qkv32[((((int64_t)2 * B + b) * H + head) * ntok + t) * 64 + d] = v;
         }
     }
@@ -331,7 +353,7 @@ static hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, 
     RowLoader<E> al{a, D};
     EpiQK<E> eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
     EpiVt<E> ev{bias, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
-    if constexpr (sizeof(E) == 2)
+    if constexpr (Elem<E>::MODE == 0)
         if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_cfg<Cfg256x256, E>(al, w, M, D, eqk, ev, s);
     const long t128 = (long)((M + 127) / 128) * (3 * D / 128);
     if (D % 128 == 0 && t128 >= 512) return launch_qkv_cfg<Cfg128x128q, E>(al, w, M, D, eqk, ev, s);
@@ -341,6 +363,9 @@ static hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, 
 
 hipError_t launch_qkv(int prec, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
                       float *qkv_f32, int batch, int n_tokens, int n_pad, int heads, hipStream_t s) {
+    if (prec == 2)
+        return launch_qkv_e<sp32>((const sp32 *)a, (const sp32 *)w, bias, (sp32 *)q, (sp32 *)k, (sp32 *)vt, qkv_f32, batch,
+                                  n_tokens, n_pad, heads, s);
     if (prec)
         return launch_qkv_e<float>((const float *)a, (const float *)w, bias, (float *)q, (float *)k, (float *)vt, qkv_f32,
                                    batch, n_tokens, n_pad, heads, s);
@@ -376,21 +401,31 @@ struct PatchLoader {
         }
         return image + (int64_t)b * sb + (int64_t)(y0 + py * p) * sy + x0 + px * p;
     }
-    __device__ __forceinline__ Raw load(Handle h, int k) const {
+    // chunk cc of K step t: bf16 -> k = 64t + 8cc .. +7; fp32 -> k = 32t + 4cc .. +3; split pairs -> the hi (cc < 4)
+    // or lo (cc >= 4) halves of k = 32t + 8(cc & 3) .. +7
+    __device__ __forceinline__ Raw load(Handle h, int t, int cc) const {
+        constexpr int MODE = Elem<E>::MODE;
+        const int k = MODE == 0 ? t * 64 + cc * 8 : MODE == 1 ? t * 32 + cc * 4 : t * 32 + (cc & 3) * 8;
         const int c = k / pp, rem = k - c * pp;
         const int dy = rem / p, dx = rem - dy * p;
         const float *ptr = h + (int64_t)c * sc + (int64_t)dy * sy + dx;
         Raw r;
         r.lo = *(const f32x4 *)ptr;
         r.hi = r.lo;
-        if (sizeof(E) == 2) r.hi = *(const f32x4 *)(ptr + 4);
+        if (MODE != 1) r.hi = *(const f32x4 *)(ptr + 4);
         return r;
     }
-    __device__ __forceinline__ static typename Elem<E>::Chunk finish(const Raw &r) {
-        if constexpr (sizeof(E) == 2)
+    __device__ __forceinline__ static typename Elem<E>::Chunk finish(const Raw &r, int cc) {
+        if constexpr (Elem<E>::MODE == 0) {
             return cvt8(r.lo, r.hi);
-        else
+        } else if constexpr (Elem<E>::MODE == 1) {
             return r.lo;
+        } else {
+            bf16x8 hi, lo;
+            split8(r.lo, r.hi, hi, lo);
+            const bf16x8 sel = cc < 4 ? hi : lo;
+            return __builtin_bit_cast(f32x4, sel);
+        }
     }
 };
 
@@ -436,6 +471,7 @@ static hipError_t launch_patch_e(const PatchArgs &pa, const E *w, const float *b
 
 hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, const float *bias, const float *pos,
                               float *x, int dim, hipStream_t s) {
+    if (prec == 2) return launch_patch_e<sp32>(pa, (const sp32 *)w, bias, pos, x, dim, s);
     if (prec) return launch_patch_e<float>(pa, (const float *)w, bias, pos, x, dim, s);
     return launch_patch_e<bf16>(pa, (const bf16 *)w, bias, pos, x, dim, s);
 }

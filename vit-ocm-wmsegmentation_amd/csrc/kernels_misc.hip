@@ -11,7 +11,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // One wavefront per row; the row lives in registers (float2 per lane per 128 columns), mean and
 // biased variance are two in-register passes (same two-pass form as ATen's CPU kernel), fp32
 // statistics. Output is bf16 (operand of the next MFMA GEMM) or fp32 (final norm -> feat).
-template <bool OUT_BF16>
+// OUT: 0 = fp32, 1 = bf16, 2 = split-bf16 pairs (common.h: sp32 rows)
+template <int OUT>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                         const float *__restrict__ beta, void *__restrict__ y,
                                                         int64_t rows, int dim, float eps) {
@@ -48,11 +49,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             const f32x2 g = *(const f32x2 *)(gamma + c), b = *(const f32x2 *)(beta + c);
             const float o0 = (v[i][0] - mean) * rstd * g[0] + b[0];
             const float o1 = (v[i][1] - mean) * rstd * g[1] + b[1];
-            if (OUT_BF16) {
+            if (OUT == 1) {
                 bf16x2 o;
                 o[0] = (bf16)o0;
                 o[1] = (bf16)o1;
                 *(bf16x2 *)((bf16 *)y + row * dim + c) = o;
+            } else if (OUT == 2) {
+                bf16 h0, l0, h1, l1;
+                split1(o0, h0, l0);
+                split1(o1, h1, l1);
+                bf16x2 hi, lo;
+                hi[0] = h0; hi[1] = h1; lo[0] = l0; lo[1] = l1;
+                char *rp = (char *)y + row * dim * 4 + sp_off(c);
+                *(bf16x2 *)rp = hi;
+                *(bf16x2 *)(rp + 64) = lo;
             } else {
                 f32x2 o = {o0, o1};
                 *(f32x2 *)((float *)y + row * dim + c) = o;
@@ -63,7 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
 // Fast path for dim % 128 == 0 (ViT-S 384, ViT-B 768): half a wavefront per row, float4 loads
 // (dim/128 per lane, all issued before the first use), 8-byte bf16 / 16-byte fp32 stores.
-template <bool OUT_BF16, int NV>
+template <int OUT, int NV>
 __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, void *__restrict__ y,
                                                            int64_t rows, float eps) {
@@ -99,11 +109,17 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float *__restri
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
-        if (OUT_BF16) {
+        if (OUT == 1) {
             bf16x4 ob;
 #pragma unroll
             for (int e = 0; e < 4; ++e) ob[e] = (bf16)o[e];
             *(bf16x4 *)((bf16 *)y + row * dim + c) = ob;
+        } else if (OUT == 2) {
+            bf16x4 hi, lo;
+            split4(o, hi, lo);
+            char *rp = (char *)y + row * dim * 4 + sp_off(c);
+            *(bf16x4 *)rp = hi;
+            *(bf16x4 *)(rp + 64) = lo;
         } else {
             *(f32x4 *)((float *)y + row * dim + c) = o;
         }
@@ -111,33 +127,39 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float *__restri
 }
 
 template <int NV>
-static hipError_t launch_ln_v4(const float *x, const float *gamma, const float *beta, void *y, bool out_bf16,
+static hipError_t launch_ln_v4(const float *x, const float *gamma, const float *beta, void *y, int out_kind,
                                int64_t rows, float eps, hipStream_t s) {
     const dim3 grid((unsigned)((rows + 7) / 8)), block(256);
-    if (out_bf16)
-        layernorm_v4_kernel<true, NV><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, eps);
+    if (out_kind == 1)
+        layernorm_v4_kernel<1, NV><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, eps);
+    else if (out_kind == 2)
+        layernorm_v4_kernel<2, NV><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, eps);
     else
-        layernorm_v4_kernel<false, NV><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, eps);
+        layernorm_v4_kernel<0, NV><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, eps);
     return hipGetLastError();
 }
 
-hipError_t launch_layernorm(const float *x, const float *gamma, const float *beta, void *y, bool out_bf16,
+// out_kind: OCM_LN_F32 (0) / OCM_LN_BF16 (1) / OCM_LN_SPLIT (2, dim % 32 == 0)
+hipError_t launch_layernorm(const float *x, const float *gamma, const float *beta, void *y, int out_kind,
                             int64_t rows, int dim, float eps, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
+    if (out_kind == 2 && dim % 32) return hipErrorInvalidValue;
     switch (dim) {
-        case 128: return launch_ln_v4<1>(x, gamma, beta, y, out_bf16, rows, eps, s);
-        case 256: return launch_ln_v4<2>(x, gamma, beta, y, out_bf16, rows, eps, s);
-        case 384: return launch_ln_v4<3>(x, gamma, beta, y, out_bf16, rows, eps, s);
-        case 512: return launch_ln_v4<4>(x, gamma, beta, y, out_bf16, rows, eps, s);
-        case 768: return launch_ln_v4<6>(x, gamma, beta, y, out_bf16, rows, eps, s);
-        case 1024: return launch_ln_v4<8>(x, gamma, beta, y, out_bf16, rows, eps, s);
+        case 128: return launch_ln_v4<1>(x, gamma, beta, y, out_kind, rows, eps, s);
+        case 256: return launch_ln_v4<2>(x, gamma, beta, y, out_kind, rows, eps, s);
+        case 384: return launch_ln_v4<3>(x, gamma, beta, y, out_kind, rows, eps, s);
+        case 512: return launch_ln_v4<4>(x, gamma, beta, y, out_kind, rows, eps, s);
+        case 768: return launch_ln_v4<6>(x, gamma, beta, y, out_kind, rows, eps, s);
+        case 1024: return launch_ln_v4<8>(x, gamma, beta, y, out_kind, rows, eps, s);
         default: break;
     }
     const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-    if (out_bf16)
-        layernorm_kernel<true><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, dim, eps);
+    if (out_kind == 1)
+        layernorm_kernel<1><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, dim, eps);
+    else if (out_kind == 2)
+        layernorm_kernel<2><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, dim, eps);
     else
-        layernorm_kernel<false><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, dim, eps);
+        layernorm_kernel<0><<<grid, block, 0, s>>>(x, gamma, beta, y, rows, dim, eps);
     return hipGetLastError();
 }
 
@@ -165,6 +187,48 @@ hipError_t launch_cast_bf16(const float *src, bf16 *dst, size_t count, hipStream
     return hipGetLastError();
 }
 
+// fp32 -> split-bf16 pairs (common.h: sp32): every 32 consecutive elements become [32 x hi | 32 x lo] (128 bytes).
+// `count` must be a multiple of 32 (all contraction extents here are). 8 elements per thread.
+__global__ __launch_bounds__(256) void cast_split_kernel(const float *__restrict__ src, char *__restrict__ dst,
+                                                         size_t count) {
+    const size_t nvec = count >> 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 a = *(const f32x4 *)(src + i * 8), b = *(const f32x4 *)(src + i * 8 + 4);
+        bf16x8 hi, lo;
+        split8(a, b, hi, lo);
+        char *g = dst + (i >> 2) * 128 + (i & 3) * 16;
+        *(bf16x8 *)g = hi;
+        *(bf16x8 *)(g + 64) = lo;
+    }
+}
+
+hipError_t launch_cast_split(const float *src, void *dst, size_t count, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    if (count % 32) return hipErrorInvalidValue;
+    size_t blocks = ((count >> 3) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    cast_split_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(src, (char *)dst, count);
+    return hipGetLastError();
+}
+
+// inverse (tests / diagnostics): split pairs -> fp32 hi + lo
+__global__ __launch_bounds__(256) void merge_split_kernel(const char *__restrict__ src, float *__restrict__ dst,
+                                                          size_t count) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) {
+        const char *g = src + (i >> 5) * 128 + (i & 31) * 2;
+        dst[i] = (float)*(const bf16 *)g + (float)*(const bf16 *)(g + 64);
+    }
+}
+
+hipError_t launch_merge_split(const void *src, float *dst, size_t count, hipStream_t s) {
+    if (count == 0) return hipSuccess;
+    if (count % 32) return hipErrorInvalidValue;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    merge_split_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>((const char *)src, dst, count);
+    return hipGetLastError();
+}
+
 // Grayscale fold of the patch-embedding conv weight: for R==G==B inputs
 // conv(x, W) == conv(x[:, :1], W.sum(dim=1)). src (D, C, pp) fp32 -> dst (D, pp) bf16.
 __global__ __launch_bounds__(256) void fold_cast_kernel(const float *__restrict__ src, bf16 *__restrict__ dst, int D,
@@ -185,6 +249,27 @@ __global__ __launch_bounds__(256) void fold_f32_kernel(const float *__restrict__
     float s = 0.f;
     for (int c = 0; c < C; ++c) s += src[((size_t)d * C + c) * pp + k];
     dst[i] = s;
+}
+
+__global__ __launch_bounds__(256) void fold_split_kernel(const float *__restrict__ src, char *__restrict__ dst, int D,
+                                                         int C, int pp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D * pp) return;
+    const int d = i / pp, k = i - d * pp;
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += src[((size_t)d * C + c) * pp + k];
+    bf16 hi, lo;
+    split1(s, hi, lo);
+    char *g = dst + (size_t)(i >> 5) * 128 + (i & 31) * 2;  // pp % 32 == 0: groups never straddle rows
+    *(bf16 *)g = hi;
+    *(bf16 *)(g + 64) = lo;
+}
+
+hipError_t launch_fold_split(const float *src, void *dst, int D, int C, int pp, hipStream_t s) {
+    const int n = D * pp;
+    if (pp % 32) return hipErrorInvalidValue;
+    fold_split_kernel<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(src, (char *)dst, D, C, pp);
+    return hipGetLastError();
 }
 
 hipError_t launch_fold_f32(const float *src, float *dst, int D, int C, int pp, hipStream_t s) {

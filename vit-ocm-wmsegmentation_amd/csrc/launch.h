@@ -4,9 +4,14 @@
 #include "common.h"
 
 // ---- kernels_misc.hip
-hipError_t launch_layernorm(const float *x, const float *gamma, const float *beta, void *y, bool out_bf16,
+// out_kind: 0 fp32, 1 bf16, 2 split-bf16 pairs
+hipError_t launch_layernorm(const float *x, const float *gamma, const float *beta, void *y, int out_kind,
                             int64_t rows, int dim, float eps, hipStream_t s);
+static inline int ln_kind_of_prec(int prec) { return prec == 0 ? 1 : prec == 1 ? 0 : 2; }
 hipError_t launch_cast_bf16(const float *src, bf16 *dst, size_t count, hipStream_t s);
+hipError_t launch_cast_split(const float *src, void *dst, size_t count, hipStream_t s);
+hipError_t launch_merge_split(const void *src, float *dst, size_t count, hipStream_t s);
+hipError_t launch_fold_split(const float *src, void *dst, int D, int C, int pp, hipStream_t s);
 // sum over the channel axis of a (D, C, p, p) conv weight -> bf16 (D, p*p): grayscale fold.
 hipError_t launch_fold_cast_bf16(const float *src, bf16 *dst, int D, int C, int pp, hipStream_t s);
 hipError_t launch_fold_f32(const float *src, float *dst, int D, int C, int pp, hipStream_t s);
@@ -14,7 +19,8 @@ hipError_t launch_cls_rows(const float *cls, const float *pos, float *x, int bat
                            hipStream_t s);
 
 // `prec` selects the operand element type of the contraction kernels: 0 = bf16 (OCM_PREC_BF16),
-// 1 = fp32 (OCM_PREC_FP32). Activation buffers (a, q, k, vt, ctx, ...) and weights are of that type.
+// 1 = fp32 (OCM_PREC_FP32), 2 = split-bf16 pairs (OCM_PREC_BF16X3, common.h: sp32). Activation buffers
+// (a, q, k, vt, ctx, ...) and weights are of that type.
 // ---- kernels_gemm.hip
 hipError_t launch_linear(int prec, const void *a, const void *w, const float *bias, const float *resid, void *out, int M,
                          int N, int K, int epilogue, hipStream_t s);
@@ -61,6 +67,9 @@ hipError_t launch_blend_u8(const uint8_t *img, const uint8_t *att, size_t count,
                            uint8_t *out, unsigned long long *hist256, hipStream_t s);
 
 static inline int ocm_round_up(int v, int m) { return (v + m - 1) / m * m; }
+// padded token count of the q / k / V^T buffers: the key axis of V^T is a contraction axis, so split pairs need whole
+// groups of 32 keys
+static inline int ocm_n_pad_for(int prec, int n) { return ocm_round_up(n, prec == 2 ? 32 : 8); }
 
 // ---- Swin (kernels_swin.hip, kernels_gemm.hip)
 hipError_t launch_linear_ld(int prec, const void *a, int64_t lda, const void *w, const float *bias, const float *resid,

@@ -29,6 +29,35 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def to_operand(x32, precision):
+    """fp32 HIP tensor -> the contraction kernels' operand type for `precision` (an _lib.OCM_PREC_* value):
+    bf16 tensor, the fp32 tensor itself, or split-bf16 pairs (an int32 tensor of the same shape: 4 bytes per
+    element, every 32 consecutive elements of the last axis stored as [32 x hi | 32 x lo])."""
+    _require_hip(x32, "operand")
+    x32 = x32.detach().to(torch.float32).contiguous()
+    if precision == _lib.OCM_PREC_FP32:
+        return x32
+    lib = _lib.load()
+    with torch.cuda.device(x32.device):
+        if precision == _lib.OCM_PREC_BF16:
+            out = torch.empty(x32.shape, dtype=torch.bfloat16, device=x32.device)
+            check(lib.ocm_op_cast_bf16(_p(x32), _p(out), x32.numel(), _stream()))
+        else:
+            if x32.shape[-1] % 32:
+                raise ValueError(f"split-bf16 operands need a last axis that is a multiple of 32, got {tuple(x32.shape)}")
+            out = torch.empty(x32.shape, dtype=torch.int32, device=x32.device)
+            check(lib.ocm_op_cast_split(_p(x32), _p(out), x32.numel(), _stream()))
+    return out
+
+
+def from_split(xs):
+    """split-bf16 pairs (int32 tensor as made by to_operand) -> fp32 values hi + lo."""
+    out = torch.empty(xs.shape, dtype=torch.float32, device=xs.device)
+    with torch.cuda.device(xs.device):
+        check(_lib.load().ocm_op_merge_split(_p(xs), _p(out), xs.numel(), _stream()))
+    return out
+
+
 class Engine:
     """Owns one ocm_vit_t handle (packed bf16/fp32 parameter copies in HBM) for one device."""
 
@@ -39,7 +68,7 @@ class Engine:
     GRAPH_AUTO_TOKENS = 8192
 
     def __init__(self, *, patch_size, in_chans, embed_dim, depth, num_heads, mlp_hidden, ln_eps, qk_scale,
-                 device, precision=_lib.OCM_PREC_BF16):
+                 device, precision=_lib.PRECISIONS[_lib.DEFAULT_PRECISION]):
         self.lib = _lib.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":

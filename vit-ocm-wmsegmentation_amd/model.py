@@ -21,7 +21,7 @@ import torch.nn as nn
 from . import _lib
 from .dino.utils import trunc_normal_
 from .dino.vision_transformer import VisionTransformer
-from .engine import _p, _require_hip, _stream
+from .engine import _p, _require_hip, _stream, to_operand
 
 
 class _FmapEncoder(VisionTransformer):
@@ -93,12 +93,7 @@ def _conv1x1_pixel_shuffle(encoder, tokens, conv, stride, cache):
     key = (conv.weight.data_ptr(), conv.weight._version, prec)
     if cache.get("key") != key:  # operand copy of the (O, D, 1, 1) weight in the engine's element type
         w32 = conv.weight.detach().reshape(O, D).to(device=dev, dtype=torch.float32).contiguous()
-        if prec == _lib.OCM_PREC_BF16:
-            w = torch.empty((O, D), dtype=torch.bfloat16, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(lib.ocm_op_cast_bf16(_p(w32), _p(w), w32.numel(), _stream()))
-        else:
-            w = w32
+        w = to_operand(w32, prec)
         bias = (conv.bias.detach() if conv.bias is not None else torch.zeros(O)).to(device=dev, dtype=torch.float32)
         cache.update(key=key, w=w, bias=bias.contiguous())
     patches = tokens[:, 1:].contiguous()  # (B, P, D) fp32: drop the CLS row
@@ -106,11 +101,7 @@ def _conv1x1_pixel_shuffle(encoder, tokens, conv, stride, cache):
     lin = torch.empty((M, O), dtype=torch.float32, device=dev)
     out = torch.empty((B, c_out, hp * stride, wp * stride), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        if prec == _lib.OCM_PREC_BF16:
-            a = torch.empty((M, D), dtype=torch.bfloat16, device=dev)
-            _lib.check(lib.ocm_op_cast_bf16(_p(patches), _p(a), patches.numel(), _stream()))
-        else:
-            a = patches
+        a = to_operand(patches.reshape(M, D), prec)
         _lib.check(lib.ocm_op_linear(prec, _p(a), _p(cache["w"]), _p(cache["bias"]), None, _p(lin), M, O, D,
                                      _lib.OCM_EPI_BIAS_F32, _stream()))
         _lib.check(lib.ocm_op_pixel_shuffle(_p(lin), _p(out), B, hp, wp, c_out, stride, _stream()))
