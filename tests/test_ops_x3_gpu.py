@@ -56,7 +56,8 @@ def test_layernorm_split_out(lib, dev, rows, dim):
     ref = F.layer_norm(x.double(), (dim,), g.double(), b.double(), 1e-6)
     ys = torch.empty((rows, dim), dtype=torch.int32, device=dev)
     _ok(lib, lib.ocm_op_layernorm(_p(x), _p(g), _p(b), _p(ys), _lib.OCM_LN_SPLIT, rows, dim, 1e-6, _s()))
-    assert (from_split(ys).double() - ref).abs().max().item() < 2e-5
+    err = (from_split(ys).double() - ref).abs()
+    assert (err <= ref.abs() * 2 ** -16 + 2e-5).all(), err.max().item()  # fp32 LayerNorm, then 2^-17 pairs
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (12608, 1536, 384), (333, 384, 1536), (70, 96, 192),
@@ -78,8 +79,8 @@ def test_linear_x3(lib, dev, M, N, K, epi):
         out = out.view(torch.int32)
     if epi == 1:
         out.copy_(resid)
-    _ok(lib, lib.ocm_op_linear(X3, _p(to_operand(a, X3)), _p(to_operand(w, X3)), _p(bias), _p(out) if epi == 1 else None,
-                               _p(out), M, N, K, epi, _s()))
+    a_s, w_s = to_operand(a, X3), to_operand(w, X3)  # named: the operands must outlive the call
+    _ok(lib, lib.ocm_op_linear(X3, _p(a_s), _p(w_s), _p(bias), _p(out) if epi == 1 else None, _p(out), M, N, K, epi, _s()))
     got = from_split(out) if act_out else out
     # operands carry 2^-17, fp32 accumulation over K terms of |a||w| ~ 0.05
     assert (got.double() - ref).abs().max().item() < 3e-5 * max(1.0, math.sqrt(K) / 8)
@@ -95,8 +96,8 @@ def test_qkv_proj_x3(lib, dev, B, N, H):
     k = torch.zeros_like(q)
     vt = torch.zeros((B * H, 64, npad), dtype=torch.int32, device=dev)
     qkv32 = torch.empty((3, B, H, N, 64), device=dev)
-    _ok(lib, lib.ocm_op_qkv_proj(X3, _p(to_operand(a, X3)), _p(to_operand(w, X3)), _p(bias), _p(q), _p(k), _p(vt),
-                                 _p(qkv32), B, N, H, _s()))
+    a_s, w_s = to_operand(a, X3), to_operand(w, X3)
+    _ok(lib, lib.ocm_op_qkv_proj(X3, _p(a_s), _p(w_s), _p(bias), _p(q), _p(k), _p(vt), _p(qkv32), B, N, H, _s()))
     ref = (a.double() @ w.double().t() + bias.double()).reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     tol = 3e-5 * max(1.0, math.sqrt(D) / 8)
     assert (qkv32.double() - ref).abs().max().item() < tol
@@ -129,11 +130,14 @@ def test_attention_x3(lib, dev, B, N, H, sharp):
     ctx = torch.full((B, N, H * 64), nan, device=dev).view(torch.int32)
     lse = torch.empty((B * H, N), device=dev)
     _ok(lib, lib.ocm_op_attention(X3, _p(qs), _p(ks), _p(vs), _p(ctx), _p(lse), B, N, H, scale, _s()))
-    assert (lse.double() - torch.logsumexp(s, -1) / math.log(2.0)).abs().max().item() < 2e-4
-    assert (from_split(ctx).double() - oref).abs().max().item() < 5e-5
+    # a score is a sum of 64 products of 2^-17-accurate operands of size ~sharp: its absolute error, and with it the
+    # relative error of every probability, grows with sharp^2 (1e-5 .. 1e-4 here; single bf16: 256x that)
+    es = sharp * sharp
+    assert (lse.double() - torch.logsumexp(s, -1) / math.log(2.0)).abs().max().item() < 1e-4 * es
+    assert (from_split(ctx).double() - oref).abs().max().item() < 4e-5 * es
     attn = torch.full((B, H, N, N), nan, device=dev)
     _ok(lib, lib.ocm_op_attention_probs(X3, _p(qs), _p(ks), _p(lse), _p(attn), B, N, H, scale, _s()))
-    assert (attn.reshape(B * H, N, N).double() - pref).abs().max().item() < 3e-5
+    assert (attn.reshape(B * H, N, N).double() - pref).abs().max().item() < 2e-5 * es
     assert (attn.sum(-1) - 1).abs().max().item() < 1e-4
     lse2 = torch.empty_like(lse)
     _ok(lib, lib.ocm_op_attention(X3, _p(qs), _p(ks), _p(vs), None, _p(lse2), B, N, H, scale, _s()))
@@ -141,4 +145,4 @@ def test_attention_x3(lib, dev, B, N, H, sharp):
     rows_idx = torch.tensor([0, N - 1, N // 2], dtype=torch.int32, device=dev)
     rows = torch.empty((B, H, 3, N - 1), device=dev)
     _ok(lib, lib.ocm_op_attention_rows(X3, _p(qs), _p(ks), _p(rows_idx), 3, _p(rows), B, N, H, scale, _s()))
-    assert (rows.double() - pref.reshape(B, H, N, N)[:, :, rows_idx.long(), 1:]).abs().max().item() < 3e-5
+    assert (rows.double() - pref.reshape(B, H, N, N)[:, :, rows_idx.long(), 1:]).abs().max().item() < 2e-5 * es
