@@ -90,6 +90,13 @@ extern "C" int ocm_prof_end(double *ms_per_class, int64_t *launches_per_class) {
     return rc;
 }
 
+extern int g_ocm_knobs[8];
+extern "C" int ocm_debug_knob(int32_t which, int32_t value) {
+    if (which < 0 || which >= 8) return fail(OCM_EINVAL, "knob %d out of range", which);
+    g_ocm_knobs[which] = value;
+    return OCM_OK;
+}
+
 extern "C" int ocm_abi_version(void) { return OCM_ABI_VERSION; }
 extern "C" const char *ocm_last_error(void) { return g_err.c_str(); }
 extern "C" int32_t ocm_n_pad(int32_t n_tokens) { return ocm_round_up(n_tokens, 8); }

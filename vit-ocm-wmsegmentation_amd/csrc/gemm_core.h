@@ -287,6 +287,130 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
     }
 }
 
+// ---- LDS-DMA main loop -----------------------------------------------------------------------------------------
+// Same tile image and MFMA step as gemm_mainloop, but the operand tiles go global -> LDS by `buffer_load ... lds`
+// (16 B per lane, 1 KiB = 8 LDS rows per wave instruction): no register slot, no ds_write, one address per KiB.
+// The DMA writes LDS linearly (wave base + lane * 16), so the chunk swizzle of lds_off() is applied on the SOURCE
+// side: lane L of the instruction that fills rows R .. R+7 fetches chunk (L & 7) ^ sw(row) of row R + (L >> 3).
+// NSTAGE LDS buffers form a ring with NSTAGE-1 K steps in flight; per step one counted `s_waitcnt vmcnt(N)` (own
+// loads of the step about to be read) and ONE raw s_barrier (everybody's loads landed + everybody is done reading
+// the buffer that is refilled next). Buffer descriptors are based at the tile's first row with the remaining
+// bytes of the matrix as the bound, so rows past M / N read as zeros and per-lane offsets stay 32-bit.
+#define OCM_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+__device__ __forceinline__ void raw_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// s_waitcnt vmcnt(younger * LPS) for 0 <= younger <= S (the count must be an immediate)
+template <int LPS, int S>
+__device__ __forceinline__ void wait_vm_steps(int younger) {
+    if constexpr (S == 0) {
+        OCM_VMCNT(0);
+    } else {
+        if (younger >= S)
+            OCM_VMCNT(S * LPS);
+        else
+            wait_vm_steps<LPS, S - 1>(younger);
+    }
+}
+
+// CNT buffer_load ... lds instructions of one wave: instruction j fills LDS rows (j * NW + wave) * 8 .. + 7 of the image
+// at `img` from the per-lane byte offsets voff[j] (+ soff, the K step) of the buffer `rs`.
+template <int CNT, int NW>
+__device__ __forceinline__ void dma_rows(__amdgpu_buffer_rsrc_t rs, char *img, const int (&voff)[CNT], int wave,
+                                         int soff) {
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+#pragma unroll
+    for (int j = 0; j < CNT; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(img + (j * NW + wave) * 1024), 16, voff[j], soff, 0, 0);
+}
+
+template <class Cfg, class E, bool SWAP, int KSTEPS, int NSTAGE>
+__device__ __forceinline__ void gemm_mainloop_dma(const E *__restrict__ A, int64_t lda, const E *__restrict__ W,
+                                                  int64_t ldw, int m0, int n0, int M, int N, int K, char *smem,
+                                                  f32x16 (&acc)[Cfg::TM][Cfg::TN], const float *__restrict__ bias) {
+    constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, NW = NT / 64;
+    constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    constexpr int A_I = BM / 8 / NW, B_I = BN / 8 / NW, LPS = A_I + B_I;  // DMA instructions per wave per K step
+    constexpr int STAGE = (BM + BN) * 128, D = NSTAGE - 1;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "each wave fills whole groups of 8 rows");
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
+    const int r = lane & 31, h = lane >> 5;
+    const int esz = (int)sizeof(E);
+    const int nsteps = KSTEPS > 0 ? KSTEPS : K / Elem<E>::KROW;
+
+    auto bound = [](int64_t rows, int64_t ld_bytes) {
+        const int64_t b = rows * ld_bytes;
+        return (unsigned)(b > 0xFFFFFFFFll ? 0xFFFFFFFFll : b);
+    };
+    const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)A + (int64_t)m0 * lda * esz), 0,
+                                                       bound(M - m0, lda * esz), 0x00020000);
+    const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)W + (int64_t)n0 * ldw * esz), 0,
+                                                       bound(N - n0, ldw * esz), 0x00020000);
+    int voffA[A_I], voffB[B_I];
+#pragma unroll
+    for (int j = 0; j < A_I; ++j) {
+        const int rho = (j * NW + wave) * 8 + (lane >> 3);
+        voffA[j] = rho * (int)(lda * esz) + (((lane & 7) ^ ((rho >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < B_I; ++j) {
+        const int rho = (j * NW + wave) * 8 + (lane >> 3);
+        voffB[j] = rho * (int)(ldw * esz) + (((lane & 7) ^ ((rho >> 1) & 7)) << 4);
+    }
+    // K step t -> stage buf (a macro, not a lambda)
+#define OCM_DMA_ISSUE(t, buf)                                                   \
+    do {                                                                        \
+        char *st_ = smem + (buf) * STAGE;                                       \
+        dma_rows<A_I, NW>(rsA, st_, voffA, wave, (t) * 128);                    \
+        dma_rows<B_I, NW>(rsB, st_ + BM * 128, voffB, wave, (t) * 128);         \
+    } while (0)
+    auto compute = [&](int buf) {
+        const char *st = smem + buf * STAGE;
+        mma_step<Cfg, E, SWAP>(st + (wm * 32) * 128, st + BM * 128 + (wn * 32) * 128, r, h, acc);
+    };
+
+    // accumulators start at the bias (see gemm_mainloop): the bias loads are issued first (oldest), the prologue
+    // DMAs next, and the accumulators are filled while those are in flight
+    float bv[TN][SWAP ? 16 : 1];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + (j * Cfg::WAVES_N + wn) * 32;
+#pragma unroll
+        for (int e = 0; e < (SWAP ? 16 : 1); ++e)
+            bv[j][e] = bias ? bias[min(nb + (SWAP ? acc_row32(e, h) : r), N - 1)] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < D; ++t)
+        if (t < nsteps) OCM_DMA_ISSUE(t, t);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = bv[j][SWAP ? e : 0];
+    int bc = 0, bi = D % NSTAGE;  // stage computed next / stage filled next
+    for (int t = 0; t < nsteps; ++t) {
+        // own DMAs of step t have landed once at most the (younger) steps t+1 .. t+D-1 are pending
+        const int younger = min(D - 1, nsteps - 1 - t);
+        wait_vm_steps<LPS, NSTAGE - 2>(younger);
+        raw_barrier();
+        if (t + D < nsteps) OCM_DMA_ISSUE(t + D, bi);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(bc);
+        bc = bc + 1 == NSTAGE ? 0 : bc + 1;
+        bi = bi + 1 == NSTAGE ? 0 : bi + 1;
+    }
+    raw_barrier();  // every wave is done reading: the epilogue may reuse the LDS
+#undef OCM_DMA_ISSUE
+}
+
 // Epilogue: after the main loop's last barrier the operand LDS is free, so the waves drop their fp32
 // accumulator tiles into a row-major LDS image and the epilogue functor reads whole 16-B / 32-B row
 // chunks back and issues full-width, fully coalesced global loads/stores with the index math done once
@@ -351,6 +475,20 @@ __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::T
             epi.template run<PassCfg<Cfg::BM, Cfg::CB, Cfg::NT>>((const float *)C, m0, n0 + j * Cfg::CB);
         }
     }
+}
+
+// LDS-DMA variant of gemm_kernel for row-major A (activations): dynamic LDS = NSTAGE * (BM + BN) * 128 bytes.
+template <class Cfg, class E, bool SWAP, int KSTEPS, int NSTAGE, class Epi>
+__global__ __launch_bounds__(Cfg::NT) void gemm_dma_kernel(const E *__restrict__ A, int64_t lda, const E *__restrict__ W,
+                                                           int64_t ldw, int M, int N, int K, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = id / tiles_n, tn = id - tm * tiles_n;
+    const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+    f32x16 acc[Cfg::TM][Cfg::TN];
+    gemm_mainloop_dma<Cfg, E, SWAP, KSTEPS, NSTAGE>(A, lda, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
+    run_epilogue<Cfg, SWAP>(acc, smem, epi, m0, n0);
 }
 
 // Generic kernel: grid = tiles_m * tiles_n workgroups (linear, XCD-remapped so the

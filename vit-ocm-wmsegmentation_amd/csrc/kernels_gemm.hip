@@ -20,6 +20,22 @@ typedef GemmCfg<64, 64, 2, 2> Cfg64x64;
 // exposed prologue of a lone workgroup does (measured: ViT-S/8 slab fc1 +7 % slower, ViT-B GEMMs 13 % faster).
 typedef GemmCfg<256, 256, 2, 4> Cfg256x256;
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember per kernel template
+// instantiation (one static mask each) on which devices it has been set.
+static hipError_t ensure_lds_optin(const void *kern, int bytes, unsigned long long &done_mask) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done_mask & bit) return hipSuccess;  // benign race: setting twice is idempotent
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) done_mask |= bit;
+    return e;
+}
+
+// development knobs (ocm_debug_knob): [0] GEMM variant override for microbenchmarks, 0 = the shipped choice
+int g_ocm_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
 static inline bool big_tiles_pay(int M, int N, int K) {
     return K >= 768 && N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) >= 512;
 }
@@ -114,13 +130,8 @@ template <class Cfg, class E, bool SWAP, int KSTEPS, class ALoad, class Epi>
 static hipError_t launch_gemm_ks(const ALoad &al, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
                                  hipStream_t s) {
     auto kern = gemm_kernel<Cfg, E, SWAP, KSTEPS, ALoad, Epi>;
-    static bool attr_set = false;  // benign race: idempotent
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           Cfg::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long optin = 0;
+    if (hipError_t e = ensure_lds_optin((const void *)kern, Cfg::LDS_BYTES, optin); e != hipSuccess) return e;
     const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
     kern<<<dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, s>>>(al, w, ldw, M, N, K, epi);
     return hipGetLastError();
@@ -146,11 +157,53 @@ static hipError_t launch_gemm(const ALoad &al, const E *w, int64_t ldw, int M, i
     return launch_gemm_ks<Cfg, E, SWAP, 0>(al, w, ldw, M, N, K, epi, s);
 }
 
+// ---- LDS-DMA staged variants (gemm_mainloop_dma) ----
+template <class Cfg, class E, int KSTEPS, int NSTAGE, class Epi>
+static hipError_t launch_gemm_dma_ks(const E *a, int64_t lda, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
+                                     hipStream_t s) {
+    auto kern = gemm_dma_kernel<Cfg, E, false, KSTEPS, NSTAGE, Epi>;
+    constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
+    static_assert(LDS <= 160 * 1024, "LDS ring exceeds the CU");
+    static unsigned long long optin = 0;
+    if (hipError_t e = ensure_lds_optin((const void *)kern, LDS, optin); e != hipSuccess) return e;
+    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
+    kern<<<dim3(tiles), dim3(Cfg::NT), LDS, s>>>(a, lda, w, ldw, M, N, K, epi);
+    return hipGetLastError();
+}
+
+template <class Cfg, class E, int NSTAGE, class Epi>
+static hipError_t launch_gemm_dma(const E *a, int64_t lda, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
+                                  hipStream_t s) {
+    if (K % Elem<E>::KROW) return hipErrorInvalidValue;
+    switch (K / Elem<E>::KROW) {
+        case 6: return launch_gemm_dma_ks<Cfg, E, 6, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
+        case 12: return launch_gemm_dma_ks<Cfg, E, 12, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
+        case 24: return launch_gemm_dma_ks<Cfg, E, 24, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
+        case 48: return launch_gemm_dma_ks<Cfg, E, 48, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
+        default: break;
+    }
+    return launch_gemm_dma_ks<Cfg, E, 0, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
+}
+
+typedef GemmCfg<256, 128, 4, 2> Cfg256x128;
+typedef GemmCfg<128, 256, 2, 4> Cfg128x256;
+
 template <int MODE, class E>
 static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, const float *resid, void *out, int M,
                                      int N, int K, hipStream_t s) {
     RowLoader<E> al{a, K};
     EpiLinear<MODE, E> epi{bias, resid, out, M, N, N};
+    if constexpr (Elem<E>::MODE != 1) {  // development: pick a DMA variant by knob
+        switch (g_ocm_knobs[0]) {
+            case 1: if (N % 256 == 0) return launch_gemm_dma<Cfg256x256, E, 2>(a, K, w, K, M, N, K, epi, s); break;
+            case 2: if (N % 128 == 0) return launch_gemm_dma<Cfg256x128, E, 3>(a, K, w, K, M, N, K, epi, s); break;
+            case 3: if (N % 256 == 0) return launch_gemm_dma<Cfg128x256, E, 3>(a, K, w, K, M, N, K, epi, s); break;
+            case 4: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s); break;
+            case 5: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128, E, 3>(a, K, w, K, M, N, K, epi, s); break;
+            case 6: if (N % 128 == 0) return launch_gemm_dma<Cfg256x128, E, 2>(a, K, w, K, M, N, K, epi, s); break;
+            default: break;
+        }
+    }
     if constexpr (Elem<E>::MODE == 0)
         if (big_tiles_pay(M, N, K)) return launch_gemm<Cfg256x256, E, false>(al, w, K, M, N, K, epi, s);
     // Tile choice: fill >= 2 workgroups per CU (256 CUs) when the problem allows it.
@@ -322,13 +375,8 @@ template <class Cfg, class E, int KSTEPS>
 static hipError_t launch_qkv_ks(const RowLoader<E> &al, const E *w, int M, int D, const EpiQK<E> &eqk,
                                 const EpiVt<E> &ev, hipStream_t s) {
     auto kern = qkv_kernel<Cfg, E, KSTEPS>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           Cfg::LDS_BYTES);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static unsigned long long optin = 0;
+    if (hipError_t e = ensure_lds_optin((const void *)kern, Cfg::LDS_BYTES, optin); e != hipSuccess) return e;
     const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((ev.vt ? 3 : 2) * D / Cfg::BN);
     kern<<<dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, s>>>(al, w, M, D, eqk, ev);
     return hipGetLastError();
