@@ -259,6 +259,9 @@ enum {
     OCM_K_COUNT = 8
 };
 int ocm_prof_begin(uint32_t class_mask, int32_t max_launches);
+/* Development knobs (microbenchmarks only; 0 = shipped behaviour): knob 0 overrides the GEMM kernel variant of
+ * ocm_op_linear (tools/microbench_x3.py). Process-wide, not thread-safe. */
+int ocm_debug_knob(int32_t which, int32_t value);
 int ocm_prof_end(double *ms_per_class /*[OCM_K_COUNT]*/, int64_t *launches_per_class /*[OCM_K_COUNT]*/);
 
 /* ---- sliding-window post-processing on device (SURVEY §8-f "next" rows 1-2; sw_processing.py) ---- */

@@ -147,6 +147,7 @@ SIGNATURES = {
     "ocm_op_head_mean": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_image_to_gray_u8": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "ocm_op_blend_u8": (C.c_int, [_vp, _vp, _i64, C.c_double, C.c_double, _vp, _vp, _vp]),
+    "ocm_debug_knob": (C.c_int, [_i32, _i32]),
     "ocm_prof_begin": (C.c_int, [C.c_uint32, _i32]),
     "ocm_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_i64)]),
     "ocm_sw_count": (_i32, [_i32, _i32]),

@@ -298,8 +298,12 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
 // bytes of the matrix as the bound, so rows past M / N read as zeros and per-lane offsets stay 32-bit.
 #define OCM_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+// Workgroup barrier that leaves the vector-memory counter alone (LDS-DMA stays in flight across it) but retires
+// this wave's own LDS reads first: once every wave has passed it, nobody is still reading the stage that the next
+// DMA overwrites (WAR), and — after the counted vmcnt wait in front of it — everybody's DMA of the stage read next
+// has landed (RAW).
 __device__ __forceinline__ void raw_barrier() {
-    asm volatile("" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 }
@@ -322,10 +326,12 @@ __device__ __forceinline__ void wait_vm_steps(int younger) {
 template <int CNT, int NW>
 __device__ __forceinline__ void dma_rows(__amdgpu_buffer_rsrc_t rs, char *img, const int (&voff)[CNT], int wave,
                                          int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)  // hipcc's HOST pass mis-handles a second instantiation context of this builtin
     typedef __attribute__((address_space(3))) void *lds_ptr;
 #pragma unroll
     for (int j = 0; j < CNT; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(img + (j * NW + wave) * 1024), 16, voff[j], soff, 0, 0);
+#endif
 }
 
 template <class Cfg, class E, bool SWAP, int KSTEPS, int NSTAGE>
