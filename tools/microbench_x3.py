@@ -43,13 +43,17 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--rows", type=int, default=12608)
     ap.add_argument("--dim", type=int, default=384)
+    ap.add_argument("--only", default="")
     a = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     M, D = a.rows, a.dim
     shapes = {"fc1": (M, 4 * D, D, 2), "fc2": (M, D, 4 * D, 1), "proj": (M, D, D, 1), "qkv_as_linear": (M, 3 * D, D, 3)}
+    only = set(filter(None, a.only.split(",")))
     for name, (m, n, k, epi) in shapes.items():
+        if only and name not in only:
+            continue
         x = torch.randn((m, k), generator=g).to(dev)
         w = (torch.randn((n, k), generator=g) * 0.02).to(dev)
         bias = torch.randn((n,), generator=g).to(dev)

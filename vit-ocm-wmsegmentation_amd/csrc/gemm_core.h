@@ -407,6 +407,9 @@ __device__ __forceinline__ void gemm_mainloop_dma(const E *__restrict__ A, int64
         const int younger = min(D - 1, nsteps - 1 - t);
         wait_vm_steps<LPS, NSTAGE - 2>(younger);
         raw_barrier();
+#ifdef OCM_GEMM_STAMPS
+        if (t == 0) STAMP(6);  // first tile landed
+#endif
         if (t + D < nsteps) OCM_DMA_ISSUE(t + D, bi);
         __builtin_amdgcn_sched_barrier(0);
         compute(bc);
@@ -493,8 +496,15 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_dma_kernel(const E *__restrict__
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
+    STAMP(0);
     gemm_mainloop_dma<Cfg, E, SWAP, KSTEPS, NSTAGE>(A, lda, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
+    STAMP(1);
     run_epilogue<Cfg, SWAP>(acc, smem, epi, m0, n0);
+    STAMP(4);
+#ifdef OCM_GEMM_STAMPS
+    __builtin_amdgcn_s_waitcnt(0);
+    STAMP(5);
+#endif
 }
 
 // Generic kernel: grid = tiles_m * tiles_n workgroups (linear, XCD-remapped so the
