@@ -182,6 +182,11 @@ def load():
         fn.argtypes = args
     if lib.ocm_abi_version() != OCM_ABI_VERSION:
         raise OcmError(f"libocm_vit ABI {lib.ocm_abi_version()} != binding ABI {OCM_ABI_VERSION}")
+    # development: OCM_KNOBS="0=4,3=-1" presets ocm_debug_knob values (A/B runs of kernel variants)
+    for item in filter(None, os.environ.get("OCM_KNOBS", "").split(",")):
+        which, value = item.split("=")
+        if lib.ocm_debug_knob(int(which), int(value)) != OCM_OK:
+            raise OcmError(f"OCM_KNOBS: bad entry {item!r}")
     _lib = lib
     return lib
 

@@ -87,6 +87,10 @@ __device__ __forceinline__ void split8(const f32x4 &a, const f32x4 &b, bf16x8 &h
 }
 // acc += a*b for split operands: small terms first
 __device__ __forceinline__ f32x16 mfma32x3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x16 c) {
+#if defined(OCM_ABL) && OCM_ABL == 1  // ablation 1: operands fetched, no matrix instructions
+    asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));
+    return c;
+#endif
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);

@@ -33,8 +33,13 @@ static hipError_t ensure_lds_optin(const void *kern, int bytes, unsigned long lo
     return e;
 }
 
-// development knobs (ocm_debug_knob): [0] GEMM variant override for microbenchmarks, 0 = the shipped choice
+// development knobs (ocm_debug_knob): [0] GEMM variant override for microbenchmarks, 0 = the shipped choice;
+// [1] start-up stagger in shader cycles, [2] stagger selection mode (gemm_core.h: stagger_start)
 int g_ocm_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+hipError_t ocm_push_stagger() {
+    const int v[2] = {g_ocm_knobs[1], g_ocm_knobs[2]};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), v, sizeof v);
+}
 
 static inline bool big_tiles_pay(int M, int N, int K) {
     return K >= 768 && N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) >= 512;
@@ -176,9 +181,7 @@ static hipError_t launch_gemm_dma(const E *a, int64_t lda, const E *w, int64_t l
                                   hipStream_t s) {
     if (K % Elem<E>::KROW) return hipErrorInvalidValue;
     switch (K / Elem<E>::KROW) {
-        case 6: return launch_gemm_dma_ks<Cfg, E, 6, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
         case 12: return launch_gemm_dma_ks<Cfg, E, 12, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
-        case 24: return launch_gemm_dma_ks<Cfg, E, 24, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
         case 48: return launch_gemm_dma_ks<Cfg, E, 48, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
         default: break;
     }
@@ -193,17 +196,24 @@ static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, 
                                      int N, int K, hipStream_t s) {
     RowLoader<E> al{a, K};
     EpiLinear<MODE, E> epi{bias, resid, out, M, N, N};
-    if constexpr (Elem<E>::MODE != 1) {  // development: pick a DMA variant by knob
-        switch (g_ocm_knobs[0]) {
+    if constexpr (Elem<E>::MODE == 2) {
+        switch (g_ocm_knobs[0]) {  // development: force a variant (tools/microbench_x3.py)
+            case -1: goto reg_staged;
             case 1: if (N % 256 == 0) return launch_gemm_dma<Cfg256x256, E, 2>(a, K, w, K, M, N, K, epi, s); break;
-            case 2: if (N % 128 == 0) return launch_gemm_dma<Cfg256x128, E, 3>(a, K, w, K, M, N, K, epi, s); break;
-            case 3: if (N % 256 == 0) return launch_gemm_dma<Cfg128x256, E, 3>(a, K, w, K, M, N, K, epi, s); break;
             case 4: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s); break;
-            case 5: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128, E, 3>(a, K, w, K, M, N, K, epi, s); break;
             case 6: if (N % 128 == 0) return launch_gemm_dma<Cfg256x128, E, 2>(a, K, w, K, M, N, K, epi, s); break;
+            case 7: if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 2>(a, K, w, K, M, N, K, epi, s); break;
+            case 8: if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 3>(a, K, w, K, M, N, K, epi, s); break;
             default: break;
         }
+        // Split-bf16 operands, >= 512 tiles of 128x128 (fc1): LDS-DMA staging, two workgroups per CU. Inside the forward
+        // (ViT-S/16, B = 64, same box, alternating runs) fc1 62 -> 57 us; the 64x128 shapes (proj, fc2) and the qkv
+        // projection measure the same either way (their stand-alone gains of 10 % do not survive cold operands), so
+        // they stay on the register-staged loop.
+        if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512)
+            return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
     }
+reg_staged:
     if constexpr (Elem<E>::MODE == 0)
         if (big_tiles_pay(M, N, K)) return launch_gemm<Cfg256x256, E, false>(al, w, K, M, N, K, epi, s);
     // Tile choice: fill >= 2 workgroups per CU (256 CUs) when the problem allows it.
@@ -362,6 +372,7 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader<E> al, const E *
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
+    stagger_start();
     if (n0 < 2 * D) {  // workgroup-uniform
         gemm_mainloop<Cfg, E, false, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
         run_epilogue<Cfg, false>(acc, smem, eqk, m0, n0);
@@ -369,6 +380,49 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader<E> al, const E *
         gemm_mainloop<Cfg, E, true, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
         run_epilogue<Cfg, true>(acc, smem, ev, m0, n0);
     }
+}
+
+// LDS-DMA staged variant (gemm_mainloop_dma); dynamic LDS = NSTAGE * (BM + BN) * 128
+template <class Cfg, class E, int KSTEPS, int NSTAGE>
+__global__ __launch_bounds__(Cfg::NT) void qkv_dma_kernel(const E *__restrict__ A, const E *__restrict__ W, int M, int D,
+                                                          EpiQK<E> eqk, EpiVt<E> ev) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int N = 3 * D, K = D;
+    const int tiles_n = (ev.vt ? N : 2 * D) / Cfg::BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    const int tm = id / tiles_n, tn = id - tm * tiles_n;
+    const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+    f32x16 acc[Cfg::TM][Cfg::TN];
+    if (n0 < 2 * D) {  // workgroup-uniform
+        gemm_mainloop_dma<Cfg, E, false, KSTEPS, NSTAGE>(A, K, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
+        run_epilogue<Cfg, false>(acc, smem, eqk, m0, n0);
+    } else {
+        gemm_mainloop_dma<Cfg, E, true, KSTEPS, NSTAGE>(A, K, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
+        run_epilogue<Cfg, true>(acc, smem, ev, m0, n0);
+    }
+}
+
+template <class Cfg, class E, int KSTEPS, int NSTAGE>
+static hipError_t launch_qkv_dma_ks(const E *a, const E *w, int M, int D, const EpiQK<E> &eqk, const EpiVt<E> &ev,
+                                    hipStream_t s) {
+    auto kern = qkv_dma_kernel<Cfg, E, KSTEPS, NSTAGE>;
+    constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
+    static unsigned long long optin = 0;
+    if (hipError_t e = ensure_lds_optin((const void *)kern, LDS, optin); e != hipSuccess) return e;
+    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((ev.vt ? 3 : 2) * D / Cfg::BN);
+    kern<<<dim3(tiles), dim3(Cfg::NT), LDS, s>>>(a, w, M, D, eqk, ev);
+    return hipGetLastError();
+}
+
+template <class Cfg, class E, int NSTAGE>
+static hipError_t launch_qkv_dma(const E *a, const E *w, int M, int D, const EpiQK<E> &eqk, const EpiVt<E> &ev,
+                                 hipStream_t s) {
+    switch (D / Elem<E>::KROW) {
+        case 12: return launch_qkv_dma_ks<Cfg, E, 12, NSTAGE>(a, w, M, D, eqk, ev, s);
+        case 24: return launch_qkv_dma_ks<Cfg, E, 24, NSTAGE>(a, w, M, D, eqk, ev, s);
+        default: break;
+    }
+    return launch_qkv_dma_ks<Cfg, E, 0, NSTAGE>(a, w, M, D, eqk, ev, s);
 }
 
 template <class Cfg, class E, int KSTEPS>
@@ -404,6 +458,16 @@ static hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, 
     if constexpr (Elem<E>::MODE == 0)
         if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_cfg<Cfg256x256, E>(al, w, M, D, eqk, ev, s);
     const long t128 = (long)((M + 127) / 128) * (3 * D / 128);
+    if constexpr (Elem<E>::MODE == 2) {
+        if (D % 128 == 0 && M > 64) {
+            switch (g_ocm_knobs[3]) {  // development: 1 / 2 / 3 force an LDS-DMA variant (same speed in the forward)
+                case 1: return launch_qkv_dma<Cfg128x128, E, 2>(a, w, M, D, eqk, ev, s);
+                case 2: return launch_qkv_dma<Cfg128x128q, E, 2>(a, w, M, D, eqk, ev, s);
+                case 3: return launch_qkv_dma<Cfg64x128, E, 2>(a, w, M, D, eqk, ev, s);
+                default: break;
+            }
+        }
+    }
     if (D % 128 == 0 && t128 >= 512) return launch_qkv_cfg<Cfg128x128q, E>(al, w, M, D, eqk, ev, s);
     if (D % 128 == 0) return launch_qkv_cfg<Cfg64x128, E>(al, w, M, D, eqk, ev, s);
     return launch_qkv_cfg<Cfg64x64, E>(al, w, M, D, eqk, ev, s);
