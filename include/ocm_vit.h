@@ -56,14 +56,15 @@ enum {
 };
 
 /* Hyper-parameters: VisionTransformer.__init__ (vision_transformer.py:137-165) and
- * the vit_tiny/small/base factories (:259-279). head_dim = embed_dim/num_heads
- * must be 64 (true for T/S/B). */
+ * the vit_tiny/small/base factories (:259-279). head_dim = embed_dim/num_heads = 64 (T/S/B) runs the MFMA attention
+ * kernels; any other multiple of 8 (the SimMIM encoder of model.py:93-103: 3 heads of 128) runs the fp32 attention
+ * of kernels_attn.hip::attn_generic_kernel. */
 typedef struct ocm_vit_config {
     int32_t patch_size;   /* p: 8 or 16 (any multiple of 8 up to 32)                   */
     int32_t in_chans;     /* 3 (reference) or 1 (grayscale-folded patch embedding)     */
     int32_t embed_dim;    /* D, multiple of 64                                         */
     int32_t depth;        /* L                                                         */
-    int32_t num_heads;    /* H = D/64                                                  */
+    int32_t num_heads;    /* H; head_dim = D/H                                         */
     int32_t mlp_hidden;   /* int(D*mlp_ratio), multiple of 64                          */
     float ln_eps;         /* 1e-6 for the DINO factories (:262,268,277)                */
     float qk_scale;       /* head_dim^-0.5 unless qk_scale was given (:71)             */
@@ -138,7 +139,7 @@ typedef struct ocm_vit_io {
     int32_t n_last;              /* n of get_intermediate_feat / get_intermediate_layers (>=1) */
     float *out_feat;             /* dev, [n_last][B][N][D]            or NULL       */
     float *out_attn;             /* dev, [n_last][B][H][N][N]         or NULL       */
-    float *out_qkv;              /* dev, [n_last][3][B][H][N][64]     or NULL       */
+    float *out_qkv;              /* dev, [n_last][3][B][H][N][hd]     or NULL       */
     float *out_tokens;           /* dev, [B][N][D]                    or NULL       */
     const int32_t *query_rows;   /* dev, [n_rows] token indices (0 = CLS) or NULL   */
     int32_t n_rows;
@@ -305,6 +306,13 @@ int ocm_op_blend_u8(const uint8_t *img, const uint8_t *att, int64_t count, doubl
  * tokens); out: (B, c_out, hp*s, wp*s) with out[b][c][y*s+i][x*s+j] = lin[b*hp*wp + y*wp + x][c*s*s + i*s + j]. */
 int ocm_op_pixel_shuffle(const float *lin, float *out, int32_t batch, int32_t hp, int32_t wp, int32_t c_out,
                          int32_t s, void *stream);
+
+/* ---- two-layer decoder of model.py:154-166: Conv2d(3x3, padding 1) as im2col + ocm_op_linear ---- */
+/* in: token-major fp32 [B][h*w][C] (C % 32 == 0); out: operand rows E [B*h*w][9*C], K index (ky*3 + kx)*C + c, zeros
+ * outside the image; relu != 0 applies max(x, 0) on the way (the nn.ReLU in front of the second convolution). The
+ * matching weight is the (O, C, 3, 3) kernel permuted to (O, 3, 3, C). */
+int ocm_op_im2col3x3(int32_t precision, const float *in, void *out, int32_t batch, int32_t h, int32_t w,
+                     int32_t channels, int32_t relu, void *stream);
 
 /* ---- sliding-window index math (host, integer; sw_processing.py:151-163) ---- */
 /* Number of windows per axis: len(range(0, size - 2*stride, stride)). */

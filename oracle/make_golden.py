@@ -197,6 +197,15 @@ def run_wrappers():
         oz = O.encoder_fmap(sd, cfg, x, S)
         orec1 = O.conv1x1_pixel_shuffle(oz, wp1["decoder.weight"], wp1["decoder.bias"], p)
         d = [maxdiff(z, oz), maxdiff(rec1, orec1)]
+        # --- LinearProbing(layer_num=2): Conv3x3 + BatchNorm (eval statistics) + ReLU + Conv3x3 + PixelShuffle
+        wp2 = synth.synth_two_layer_decoder_params(D, p, seed=c["seed"])
+        lp2 = ref["LinearProbing"](enc, p, layer_num=2).eval()
+        msg = lp2.two_layer_decoder.load_state_dict(wp2, strict=False)
+        assert not msg.unexpected_keys and set(msg.missing_keys) <= {"1.num_batches_tracked"}
+        with torch.no_grad():
+            rec2 = lp2(x)
+        orec2 = O.two_layer_decoder(oz, wp2, p)
+        d.append(maxdiff(rec2, orec2))
         # --- VisionTransformerForSimMIM + MIM
         wp3 = synth.synth_wrapper_params(D, p, 3, seed=c["seed"])
         enc_m = ref["VisionTransformerForSimMIM"](**kw)
@@ -218,6 +227,7 @@ def run_wrappers():
         worst = max(worst, max(d))
         out[name + "_fmap"] = z.numpy()
         out[name + "_rec1"] = rec1.numpy()
+        out[name + "_rec2"] = rec2.numpy()
         out[name + "_fmap_masked"] = zm.numpy()
         out[name + "_rec3"] = rec3.numpy()
         out[name + "_loss"] = np.float64(float(loss))

@@ -169,10 +169,17 @@ def sliding_window_origins(height, width, stride):
 
 
 def sliding_window_crops(image_chw, stride, window):
-    """The crops of sw_processing.py:157-160 as a (T, C, window, window) tensor (PIL crop ==
-    array slice for in-bounds boxes)."""
+    """The crops of sw_processing.py:157-160 as a (T, C, window, window) tensor. PIL's Image.crop returns the
+    array slice for in-bounds boxes and ZERO-fills whatever part of the box lies outside the image (windows
+    of a slab whose side is not a multiple of the stride, or window > 3 * stride); pinned against PIL itself in
+    tests/test_host_logic.py::test_out_of_bounds_windows_are_zero_filled_like_pil_crop."""
     _, H, W = image_chw.shape
-    return torch.stack([image_chw[:, y:y + window, x:x + window] for y, x in sliding_window_origins(H, W, stride)])
+    origins = sliding_window_origins(H, W, stride)
+    pad_h = max(0, max(y for y, _ in origins) + window - H) if origins else 0
+    pad_w = max(0, max(x for _, x in origins) + window - W) if origins else 0
+    if pad_h or pad_w:
+        image_chw = F.pad(image_chw, (0, pad_w, 0, pad_h))
+    return torch.stack([image_chw[:, y:y + window, x:x + window] for y, x in origins])
 
 
 def blend_overlap(a, b, axis):
@@ -341,6 +348,16 @@ def encoder_fmap(sd, cfg, x, img_size, mask=None, mask_token=None):
 def conv1x1_pixel_shuffle(z, weight, bias, stride):
     """nn.Sequential(Conv2d(D, s*s*c, 1), PixelShuffle(s)) of model.py:60-66,147-152."""
     return F.pixel_shuffle(F.conv2d(z, weight, bias), stride)
+
+
+def two_layer_decoder(z, prm, stride, bn_eps=1e-5):
+    """LinearProbing.two_layer_decoder in eval mode (model.py:154-166): Conv2d(3x3, pad 1) -> BatchNorm2d (running
+    statistics) -> ReLU -> Conv2d(3x3, pad 1) -> PixelShuffle(stride). `prm`: synth.synth_two_layer_decoder_params."""
+    y = F.conv2d(z, prm["0.weight"], prm["0.bias"], padding=1)
+    y = F.batch_norm(y, prm["1.running_mean"], prm["1.running_var"], prm["1.weight"], prm["1.bias"], False, 0.0, bn_eps)
+    y = F.relu(y)
+    y = F.conv2d(y, prm["3.weight"], prm["3.bias"], padding=1)
+    return F.pixel_shuffle(y, stride)
 
 
 def mim_forward(sd, cfg, x, mask, img_size, mask_token, dec_w, dec_b, stride, patch_size=8, in_chans=3):

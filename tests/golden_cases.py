@@ -28,6 +28,8 @@ CASES = {
 WRAPPER_CASES = {
     "wrap_p8_64": dict(dim=128, depth=2, heads=2, patch=8, img_size=64, batch=2, seed=11, variant="full"),
     "wrap_p16_224": dict(dim=128, depth=2, heads=2, patch=16, img_size=224, batch=1, seed=12, variant="sharp"),
+    # the reference's own build_model() encoder (model.py:93-103): depth 4, THREE heads of 128 channels
+    "wrap_mim_hd128": dict(dim=384, depth=4, heads=3, patch=8, img_size=64, batch=2, seed=13, variant="sharp"),
 }
 
 

@@ -72,6 +72,21 @@ def test_sliding_window_origins_match_reference_golden():
         assert np.array_equal(sw_processing.sliding_window_origins(size, size, 128), gold[f"sw_origins_{size}"])
 
 
+def test_out_of_bounds_windows_are_zero_filled_like_pil_crop():
+    """sw_processing.py:157-160 crops with PIL; a slab whose side is not a multiple of the stride (or window > 3*stride)
+    has windows that reach past the image, which PIL zero-fills. The oracle's crops must equal PIL's."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for size, stride, window in ((200, 32, 96), (160, 32, 128)):  # 200: not a multiple; 160/128: window = 4 * stride
+        arr = rng.integers(1, 255, (size, size), dtype=np.uint8)
+        img = Image.fromarray(arr)
+        origins = O.sliding_window_origins(size, size, stride)
+        assert max(y for y, _ in origins) + window > size  # the case under test
+        pil = np.stack([np.asarray(img.crop((x, y, x + window, y + window))) for y, x in origins])
+        ours = O.sliding_window_crops(torch.from_numpy(arr.astype(np.float32))[None], stride, window)[:, 0].numpy()
+        assert np.array_equal(pil.astype(np.float32), ours)
+
+
 def test_sliding_window_rectangular():
     ref = O.sliding_window_origins(768, 1152, 128)
     got = sw_processing.sliding_window_origins(768, 1152, 128)

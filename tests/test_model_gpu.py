@@ -245,6 +245,25 @@ def test_sliding_window_single_rank(dev):
     assert float((maps[:, :, 0] - full).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("size,stride,window", [(200, 32, 96), (160, 32, 128), (130, 32, 96)])
+def test_sliding_window_past_the_slab_edge(dev, size, stride, window):
+    """Slabs whose side is not a multiple of the stride / windows wider than 3 strides: the last windows reach past the
+    image and the reference's PIL crop zero-fills them (sw_processing.py:157-160). The device gather must see the same
+    pixels (it used to read past the slab)."""
+    case = CASES["tiny_p8"]
+    model = build_module(case, dev)
+    sd = case_state_dict(case)
+    cfg = O.make_cfg(sd, 8, 2)
+    slab = synth.synth_tiles(1, size, seed=7)[0]
+    crops = O.sliding_window_crops(slab, stride, window)
+    sweep = SlidingWindowAttention(model, window=window, stride=stride, batch_tiles=5)
+    maps = sweep(slab.to(dev))
+    hf = window // 8
+    assert maps.shape == (crops.shape[0], 2, 1, hf, hf)
+    ref = O.get_last_selfattention(sd, cfg, crops)[:, :, 0, 1:].reshape(-1, 2, hf, hf)
+    assert float((maps[:, :, 0].cpu() - ref).abs().max()) <= 1e-5
+
+
 @pytest.mark.gpu
 def test_hip_graph_replay_matches_plain_launches(dev):
     """OCM_USE_GRAPH: the one-tile-per-call loop of the reference's scripts replays a cached hipGraph; results are

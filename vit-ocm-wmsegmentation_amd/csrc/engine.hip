@@ -124,6 +124,7 @@ struct BlockP {
 struct ocm_vit {
     ocm_vit_config cfg;
     int D, H, L, M, p, C, Kpe;
+    int hd;    // head_dim: 64 runs the MFMA attention kernels, anything else the generic fp32 attention (model.py:96-97)
     int prec;  // 0 = bf16 operands, 1 = fp32 operands, 2 = split-bf16 pairs (element size esz of matrices / activations)
     size_t esz;
     std::vector<Param> params;
@@ -156,7 +157,8 @@ extern "C" int ocm_vit_create(const ocm_vit_config *cfg, ocm_vit_t **out) {
     if (!cfg || !out) return fail(OCM_EINVAL, "ocm_vit_create: null argument");
     const int D = cfg->embed_dim, H = cfg->num_heads, p = cfg->patch_size, C = cfg->in_chans;
     if (D <= 0 || D % 64 || D > 1024) return fail(OCM_EINVAL, "embed_dim %d must be a multiple of 64, <= 1024", D);
-    if (H <= 0 || D != H * 64) return fail(OCM_EINVAL, "head_dim must be 64 (embed_dim %d, num_heads %d)", D, H);
+    if (H <= 0 || D % H || (D / H) % 8 || D / H > 512)
+        return fail(OCM_EINVAL, "head_dim = embed_dim / num_heads must be a multiple of 8, <= 512 (embed_dim %d, num_heads %d)", D, H);
     if (p < 8 || p % 8 || p > 32) return fail(OCM_EINVAL, "patch_size %d must be 8, 16, 24 or 32", p);
     if (C != 1 && C != 3) return fail(OCM_EINVAL, "in_chans %d must be 1 or 3", C);
     if ((C * p * p) % 64) return fail(OCM_EINVAL, "in_chans*patch_size^2 = %d must be a multiple of 64", C * p * p);
@@ -167,6 +169,7 @@ extern "C" int ocm_vit_create(const ocm_vit_config *cfg, ocm_vit_t **out) {
         return fail(OCM_EINVAL, "precision %d is not one of OCM_PREC_BF16 / OCM_PREC_FP32 / OCM_PREC_BF16X3", cfg->precision);
     ocm_vit *h = new ocm_vit();
     h->cfg = *cfg;
+    h->hd = D / H;
     h->D = D; h->H = H; h->L = cfg->depth; h->M = cfg->mlp_hidden; h->p = p; h->C = C; h->Kpe = C * p * p;
     h->prec = cfg->precision;  // OCM_PREC_* values are the kernels' `prec` selector
     h->esz = h->prec ? 4 : 2;
@@ -279,6 +282,7 @@ struct Workspace {  // E = bf16 (OCM_PREC_BF16) or float (OCM_PREC_FP32)
     void *ctx;    // [T][D] E attention output, heads merged
     void *hid;    // [T][M] E GELU(fc1)
     float *lse;   // [B*H][N]
+    float *qkv32; // [3][B][H][N][hd] fp32: the qkv tensor of heads that are not 64 wide (then q / k / vt are unused)
     size_t bytes;
 };
 
@@ -294,9 +298,15 @@ static Workspace carve(const ocm_vit *h, int batch, int n, char *base) {
     const size_t e = h->esz;
     w.x = (float *)take(T * h->D * 4);
     w.xn = take(T * h->D * e);
-    w.q = take(BH * np * 64 * e);
-    w.k = take(BH * np * 64 * e);
-    w.vt = take(BH * np * 64 * e);
+    w.q = w.k = w.vt = nullptr;
+    w.qkv32 = nullptr;
+    if (h->hd == 64) {
+        w.q = take(BH * np * 64 * e);
+        w.k = take(BH * np * 64 * e);
+        w.vt = take(BH * np * 64 * e);
+    } else {
+        w.qkv32 = (float *)take(3 * T * h->D * 4);
+    }
     w.ctx = take(T * h->D * e);
     w.hid = take(T * h->M * e);
     w.lse = (float *)take(BH * n * 4);
@@ -331,8 +341,15 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     // y = attn(norm1(x))
     { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, lnk, T, D, eps, s)); }
     // a block that stops after its probabilities (get_last_selfattention) and returns no qkv never reads V
-    void *vt_dst = (attn_only && !out_qkv) ? nullptr : w.vt;
-    { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, vt_dst, out_qkv, batch, n, np, H, s)); }
+    const bool want_v = !(attn_only && !out_qkv);
+    if (h->hd != 64) {  // generic heads: fp32 qkv tensor -> fp32 FMA attention
+        float *qkv = out_qkv ? out_qkv : w.qkv32;
+        { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_w), h->ptr<float>(bp.qkv_b), nullptr, nullptr, nullptr, qkv, batch, n, np, H, h->hd, want_v, s)); }
+        { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention_generic(pc, qkv, attn_only ? nullptr : w.ctx, out_attn, query_rows, n_rows, out_rows, batch, n, H, h->hd, scale, s)); }
+        if (attn_only) return OCM_OK;
+    } else {
+    void *vt_dst = want_v ? w.vt : nullptr;
+    { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, vt_dst, out_qkv, batch, n, np, H, 64, want_v, s)); }
     // selected query rows: a slice of the probabilities when those are materialised for this block anyway,
     // else their own fp32 dot-product kernel (never the (H,N,N) matrix)
     if (out_rows && !out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s)); }
@@ -348,6 +365,7 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     if (out_attn) {
         { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
         if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
+    }
     }
     // x = x + proj(ctx)
     { PROF(OCM_K_PROJ, s); HIP_TRY(launch_linear(pc, w.ctx, h->ptr<char>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s)); }
@@ -432,7 +450,7 @@ static int enqueue_forward(ocm_vit *h, const ocm_vit_io *io, int n, hipStream_t 
         const int slot = i - (L - io->n_last);  // >= 0 for the returned blocks
         const bool ret = slot >= 0, last = i == L - 1;
         float *oa = (ret && (fl & OCM_OUT_ATTN)) ? io->out_attn + (size_t)slot * B * h->H * n * n : nullptr;
-        float *oq = (ret && (fl & OCM_OUT_QKV)) ? io->out_qkv + (size_t)slot * 3 * B * h->H * n * 64 : nullptr;
+        float *oq = (ret && (fl & OCM_OUT_QKV)) ? io->out_qkv + (size_t)slot * 3 * B * h->H * n * h->hd : nullptr;
         float *orow = (last && (fl & OCM_OUT_ROWS)) ? io->out_rows : nullptr;
         if ((rc = run_block(h, i, w, w.x, B, n, attn_only && last, oa, oq, io->query_rows, io->n_rows, orow, s)))
             return rc;
@@ -605,7 +623,7 @@ extern "C" int ocm_op_qkv_proj(int32_t precision, const void *a, const void *w, 
     if (rc) return rc;
     if (!a || !w || !bias || !q || !k || !vt) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_qkv(pc, a, w, bias, q, k, vt, qkv_f32, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, (hipStream_t)stream));
+    HIP_TRY(launch_qkv(pc, a, w, bias, q, k, vt, qkv_f32, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, 64, true, (hipStream_t)stream));
     return OCM_OK;
 }
 
@@ -721,6 +739,17 @@ extern "C" int ocm_op_pixel_shuffle(const float *lin, float *out, int32_t batch,
     if (!lin || !out) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || hp <= 0 || wp <= 0 || c_out <= 0 || sh <= 0) return fail(OCM_EINVAL, "bad shape");
     HIP_TRY(launch_pixel_shuffle(lin, out, batch, hp, wp, c_out, sh, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_im2col3x3(int32_t precision, const float *in, void *out, int32_t batch, int32_t h, int32_t w,
+                                int32_t channels, int32_t relu, void *stream) {
+    int pc = 0, rc = prec_of(precision, &pc);
+    if (rc) return rc;
+    if (!in || !out) return fail(OCM_EINVAL, "null argument");
+    if (batch <= 0 || h <= 0 || w <= 0 || channels <= 0 || channels % 32)
+        return fail(OCM_EINVAL, "bad shape batch=%d h=%d w=%d channels=%d (channels %% 32)", batch, h, w, channels);
+    HIP_TRY(launch_im2col3x3(pc, in, out, batch, h, w, channels, relu, (hipStream_t)stream));
     return OCM_OK;
 }
 

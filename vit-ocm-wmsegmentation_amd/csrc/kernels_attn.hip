@@ -842,6 +842,124 @@ __global__ __launch_bounds__(256) void attn_probs_x3_kernel(const char *__restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Heads that are not 64 channels wide (the reference's SimMIM pre-training encoder, model.py:93-103: 3 heads of 128):
+// plain fp32 FMA attention on the fp32 (3,B,H,N,hd) qkv tensor, one wavefront per query row. Not a hot path —
+// correctness-grade for every precision mode (the arithmetic is fp32 whatever the GEMMs' operand type is).
+//   scores: lanes over keys (each lane walks one K row), q broadcast from LDS;  softmax: wave reductions;
+//   context: lanes over d, p broadcast from LDS, V rows read coalesced.
+__device__ __forceinline__ void store_ctx1(int prec, char *rowp, int col, float v) {
+    if (prec == 0) {
+        *(bf16 *)(rowp + col * 2) = (bf16)v;
+    } else if (prec == 1) {
+        *(float *)(rowp + col * 4) = v;
+    } else {
+        bf16 hi, lo;
+        split1(v, hi, lo);
+        *(bf16 *)(rowp + sp_off(col)) = hi;
+        *(bf16 *)(rowp + sp_off(col) + 64) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void attn_generic_kernel(const float *__restrict__ qkv, char *__restrict__ ctx,
+                                                           float *__restrict__ attn, const int32_t *__restrict__ query_rows,
+                                                           int n_rows, float *__restrict__ rows, int B, int H, int N,
+                                                           int hd, float scale, int prec, bool all_queries) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *qs = (float *)smem + wave * (hd + N);  // this wave's query, then its N scores / probabilities
+    float *sc = qs + hd;
+    const int bh = blockIdx.y, b = bh / H, head = bh - b * H;
+    const int qi = blockIdx.x * 4 + wave;
+    const int nq = all_queries ? N : n_rows;
+    if (qi >= nq) return;  // no workgroup barriers in this kernel
+    const int query = all_queries ? qi : (query_rows ? query_rows[qi] : 0);
+    const size_t plane = (size_t)B * H * N * hd;
+    const float *Q = qkv + ((size_t)bh * N + query) * hd;
+    const float *K = qkv + plane + (size_t)bh * N * hd;
+    const float *V = qkv + 2 * plane + (size_t)bh * N * hd;
+    for (int d = lane; d < hd; d += 64) qs[d] = Q[d];
+    __builtin_amdgcn_wave_barrier();
+    float mx = -INFINITY;
+    for (int key = lane; key < N; key += 64) {
+        const float *kp = K + (size_t)key * hd;
+        float acc = 0.f;
+        for (int d = 0; d < hd; d += 4) {
+            const f32x4 kv = *(const f32x4 *)(kp + d), qv = *(const f32x4 *)(qs + d);
+            acc = fmaf(qv[0], kv[0], acc);
+            acc = fmaf(qv[1], kv[1], acc);
+            acc = fmaf(qv[2], kv[2], acc);
+            acc = fmaf(qv[3], kv[3], acc);
+        }
+        acc *= scale;
+        sc[key] = acc;
+        mx = fmaxf(mx, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int key = lane; key < N; key += 64) {
+        const float p = __expf(sc[key] - mx);
+        sc[key] = p;
+        sum += p;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.0f / sum;
+    for (int key = lane; key < N; key += 64) sc[key] *= inv;
+    __builtin_amdgcn_wave_barrier();
+    if (attn && all_queries) {
+        float *dst = attn + ((size_t)bh * N + query) * N;
+        for (int key = lane; key < N; key += 64) dst[key] = sc[key];
+    }
+    if (rows) {  // selected rows with the CLS column dropped (utils.py:232)
+        if (all_queries) {
+            for (int r = 0; r < n_rows; ++r)
+                if ((query_rows ? query_rows[r] : 0) == query) {
+                    float *dst = rows + ((size_t)bh * n_rows + r) * (N - 1);
+                    for (int key = 1 + lane; key < N; key += 64) dst[key - 1] = sc[key];
+                }
+        } else {
+            float *dst = rows + ((size_t)bh * n_rows + qi) * (N - 1);
+            for (int key = 1 + lane; key < N; key += 64) dst[key - 1] = sc[key];
+        }
+    }
+    if (ctx && all_queries) {
+        char *rowp = ctx + ((size_t)b * N + query) * (size_t)(H * hd) * (prec ? 4 : 2);
+        for (int d = lane; d < hd; d += 64) {
+            float acc = 0.f;
+            for (int key = 0; key < N; ++key) acc = fmaf(sc[key], V[(size_t)key * hd + d], acc);
+            store_ctx1(prec, rowp, head * hd + d, acc);
+        }
+    }
+}
+
+hipError_t launch_attention_generic(int prec, const float *qkv, void *ctx, float *attn, const int32_t *query_rows,
+                                    int n_rows, float *rows, int batch, int n_tokens, int heads, int head_dim, float scale,
+                                    hipStream_t s) {
+    if (head_dim % 4 || head_dim > 512 || n_tokens > 8192) return hipErrorInvalidValue;
+    if (prec == 2 && (heads * head_dim) % 32) return hipErrorInvalidValue;
+    const bool all = ctx || attn;
+    const int nq = all ? n_tokens : n_rows;
+    if (nq <= 0) return hipSuccess;
+    const size_t lds = (size_t)4 * (head_dim + n_tokens) * sizeof(float);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    static unsigned long long optin_mask = 0;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    if (lds > 64 * 1024 && !(optin_mask >> (dev & 63) & 1)) {
+        if (hipError_t e = hipFuncSetAttribute((const void *)attn_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               160 * 1024);
+            e != hipSuccess)
+            return e;
+        optin_mask |= 1ull << (dev & 63);
+    }
+    attn_generic_kernel<<<dim3((nq + 3) / 4, batch * heads), dim3(256), lds, s>>>(
+        qkv, (char *)ctx, attn, query_rows, n_rows, rows, batch, heads, n_tokens, head_dim, scale, prec, all);
+    return hipGetLastError();
+}
+
 hipError_t launch_attention(int prec, const void *q, const void *k, const void *vt, void *ctx, float *lse2, int batch,
                             int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
     if (!prec)

@@ -286,9 +286,9 @@ hipError_t launch_linear(int prec, const void *a, const void *w, const float *bi
 template <class E>
 struct EpiQK {
     const float *bias;
-    E *q, *k;
-    float *qkv32;  // optional (3,B,H,N,64) fp32, or nullptr
-    int M, ntok, npad, H, D, B;
+    E *q, *k;      // head-major operand copies (head_dim 64 only), or nullptr
+    float *qkv32;  // optional (3,B,H,N,hd) fp32, or nullptr
+    int M, ntok, npad, H, D, B, hd;
     // C is [BM][BN] (rows = tokens). One lane moves 8 consecutive head-dim columns of one token. A lane keeps its
     // column chunk for the whole tile and walks the rows in constant steps, so which / head / d are computed once
     // and (image b, token t) advance incrementally: no integer division per chunk.
@@ -299,7 +299,7 @@ struct EpiQK {
         constexpr int RSTEP = NT / CPR, ITERS = BM / RSTEP;
         const int col = (threadIdx.x % CPR) * 8, row0 = threadIdx.x / CPR;
         const int n = n0 + col;
-        const int which = n / D, rem = n - which * D, head = rem >> 6, d = rem & 63;
+        const int which = n / D, rem = n - which * D, head = rem / hd, d = rem - head * hd;
         int m = m0 + row0;
         int b = m / ntok, t = m - b * ntok;
         E *base = which ? k : q;
@@ -309,15 +309,17 @@ struct EpiQK {
             const int row = row0 + i * RSTEP;
             const f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
             const f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4);
-            char *rowp = (char *)base + ((int64_t)(b * H + head) * npad + t) * 64 * (int)sizeof(E);
-            if (Elem<E>::EPW == 8) {
-                store_act((E *)nullptr, rowp, d, v0, v1);
-            } else {
-                store_act((E *)nullptr, rowp, d, v0, v0);
-                store_act((E *)nullptr, rowp, d + 4, v1, v1);
+            if (base) {
+                char *rowp = (char *)base + ((int64_t)(b * H + head) * npad + t) * 64 * (int)sizeof(E);
+                if (Elem<E>::EPW == 8) {
+                    store_act((E *)nullptr, rowp, d, v0, v1);
+                } else {
+                    store_act((E *)nullptr, rowp, d, v0, v0);
+                    store_act((E *)nullptr, rowp, d + 4, v1, v1);
+                }
             }
             if (qkv32) {
-                float *o = qkv32 + ((((int64_t)which * B + b) * H + head) * ntok + t) * 64 + d;
+                float *o = qkv32 + ((((int64_t)which * B + b) * H + head) * ntok + t) * hd + d;
                 *(f32x4 *)o = v0;
                 *(f32x4 *)(o + 4) = v1;
             }
@@ -334,9 +336,10 @@ struct EpiQK {
 template <class E>
 struct EpiVt {
     const float *bias;
-    E *vt;
+    E *vt;  // key-contiguous V^T (head_dim 64 only); a null vt with a non-null qkv32 still computes the V third
     float *qkv32;
-    int M, ntok, npad, H, D, B;
+    int M, ntok, npad, H, D, B, hd;
+    bool want_v;  // compute the V third at all
     // C is the TRANSPOSED tile [BN][BM] (rows = features n, columns = tokens m). Consecutive lanes
     // take consecutive tokens of one feature row, so each store instruction writes contiguous runs
     // of V^T (vt[(b*H+head)][d][t], t contiguous).
@@ -352,10 +355,10 @@ struct EpiVt {
         const int rem0 = n0 - 2 * D;
 #pragma unroll 4
         for (int row = threadIdx.x / BM; row < BN; row += RS) {
-            const int rem = rem0 + row, head = rem >> 6, d = rem & 63;
+            const int rem = rem0 + row, head = rem / hd, d = rem - head * hd;
             const float v = C[row * BM + col];
-            store_act1((E *)nullptr, (char *)vt + ((int64_t)(b * H + head) * 64 + d) * npad * (int)sizeof(E), t, v);
-            if (qkv32) qkv32[((((int64_t)2 * B + b) * H + head) * ntok + t) * 64 + d] = v;
+            if (vt) store_act1((E *)nullptr, (char *)vt + ((int64_t)(b * H + head) * 64 + d) * npad * (int)sizeof(E), t, v);
+            if (qkv32) qkv32[((((int64_t)2 * B + b) * H + head) * ntok + t) * hd + d] = v;
         }
     }
 };
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader<E> al, const E *
     const int N = 3 * D, K = D;
     // D % BN == 0 is checked by the launcher; without a V^T destination (a block that stops after its
     // attention probabilities) the V third of the projection is not computed at all
-    const int tiles_n = (ev.vt ? N : 2 * D) / Cfg::BN;
+    const int tiles_n = (ev.want_v ? N : 2 * D) / Cfg::BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_dma_kernel(const E *__restrict__ 
                                                           EpiQK<E> eqk, EpiVt<E> ev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int N = 3 * D, K = D;
-    const int tiles_n = (ev.vt ? N : 2 * D) / Cfg::BN;
+    const int tiles_n = (ev.want_v ? N : 2 * D) / Cfg::BN;
     const int id = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
@@ -409,7 +412,7 @@ static hipError_t launch_qkv_dma_ks(const E *a, const E *w, int M, int D, const 
     constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
     static unsigned long long optin = 0;
     if (hipError_t e = ensure_lds_optin((const void *)kern, LDS, optin); e != hipSuccess) return e;
-    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((ev.vt ? 3 : 2) * D / Cfg::BN);
+    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((ev.want_v ? 3 : 2) * D / Cfg::BN);
     kern<<<dim3(tiles), dim3(Cfg::NT), LDS, s>>>(a, w, M, D, eqk, ev);
     return hipGetLastError();
 }
@@ -431,7 +434,7 @@ static hipError_t launch_qkv_ks(const RowLoader<E> &al, const E *w, int M, int D
     auto kern = qkv_kernel<Cfg, E, KSTEPS>;
     static unsigned long long optin = 0;
     if (hipError_t e = ensure_lds_optin((const void *)kern, Cfg::LDS_BYTES, optin); e != hipSuccess) return e;
-    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((ev.vt ? 3 : 2) * D / Cfg::BN);
+    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((ev.want_v ? 3 : 2) * D / Cfg::BN);
     kern<<<dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, s>>>(al, w, M, D, eqk, ev);
     return hipGetLastError();
 }
@@ -450,11 +453,13 @@ static hipError_t launch_qkv_cfg(const RowLoader<E> &al, const E *w, int M, int 
 
 template <class E>
 static hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E *vt, float *qkv_f32, int batch,
-                               int n_tokens, int n_pad, int heads, hipStream_t s) {
-    const int D = heads * 64, M = batch * n_tokens;
+                               int n_tokens, int n_pad, int heads, int head_dim, bool want_v, hipStream_t s) {
+    const int D = heads * head_dim, M = batch * n_tokens;
+    if (head_dim != 64 && (q || k || vt)) return hipErrorInvalidValue;  // operand copies exist for 64-channel heads only
+    if (head_dim % 8) return hipErrorInvalidValue;                      // a lane's 8 columns stay inside one head
     RowLoader<E> al{a, D};
-    EpiQK<E> eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
-    EpiVt<E> ev{bias, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch};
+    EpiQK<E> eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch, head_dim};
+    EpiVt<E> ev{bias, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch, head_dim, want_v};
     if constexpr (Elem<E>::MODE == 0)
         if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_cfg<Cfg256x256, E>(al, w, M, D, eqk, ev, s);
     const long t128 = (long)((M + 127) / 128) * (3 * D / 128);
@@ -474,15 +479,16 @@ static hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, 
 }
 
 hipError_t launch_qkv(int prec, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
-                      float *qkv_f32, int batch, int n_tokens, int n_pad, int heads, hipStream_t s) {
+                      float *qkv_f32, int batch, int n_tokens, int n_pad, int heads, int head_dim, bool want_v,
+                      hipStream_t s) {
     if (prec == 2)
         return launch_qkv_e<sp32>((const sp32 *)a, (const sp32 *)w, bias, (sp32 *)q, (sp32 *)k, (sp32 *)vt, qkv_f32, batch,
-                                  n_tokens, n_pad, heads, s);
+                                  n_tokens, n_pad, heads, head_dim, want_v, s);
     if (prec)
         return launch_qkv_e<float>((const float *)a, (const float *)w, bias, (float *)q, (float *)k, (float *)vt, qkv_f32,
-                                   batch, n_tokens, n_pad, heads, s);
+                                   batch, n_tokens, n_pad, heads, head_dim, want_v, s);
     return launch_qkv_e<bf16>((const bf16 *)a, (const bf16 *)w, bias, (bf16 *)q, (bf16 *)k, (bf16 *)vt, qkv_f32, batch,
-                              n_tokens, n_pad, heads, s);
+                              n_tokens, n_pad, heads, head_dim, want_v, s);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -349,3 +349,67 @@ hipError_t launch_pixel_shuffle(const float *lin, float *out, int batch, int hp,
     pixel_shuffle_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(lin, out, hp, wp, c_out, sh, total);
     return hipGetLastError();
 }
+
+// ---- 3x3 / padding 1 convolution as a GEMM (LinearProbing's two-layer decoder, model.py:154-166) ----
+// in: token-major fp32 [B][h*w][C]; out: operand rows [B*h*w][9*C] with K index (ky*3 + kx)*C + c, zero outside the
+// image, optional ReLU on the way (the nn.ReLU between the two convolutions). One thread = 8 consecutive channels
+// of one (token, tap); C % 32 == 0 keeps every 8-channel run inside one split-pair group.
+template <int OUT>  // 0 fp32, 1 bf16, 2 split pairs
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const float *__restrict__ in, char *__restrict__ out, int B, int h,
+                                                        int w, int C, int relu) {
+    const int c8 = C >> 3;
+    const size_t total = (size_t)B * h * w * 9 * c8;
+    const int esz = OUT == 1 ? 2 : 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cc = (int)(i % c8);
+        size_t r = i / c8;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int x = (int)(r % w);
+        r /= w;
+        const int y = (int)(r % h), b = (int)(r / h);
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+            const float *src = in + (((size_t)b * h + yy) * w + xx) * C + cc * 8;
+            v0 = *(const f32x4 *)src;
+            v1 = *(const f32x4 *)(src + 4);
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] = fmaxf(v0[e], 0.f);
+                    v1[e] = fmaxf(v1[e], 0.f);
+                }
+            }
+        }
+        const size_t row = ((size_t)b * h + y) * w + x;
+        char *rowp = out + row * (size_t)(9 * C) * esz;
+        const int col = tap * C + cc * 8;
+        if (OUT == 1) {
+            *(bf16x8 *)(rowp + col * 2) = cvt8(v0, v1);
+        } else if (OUT == 0) {
+            *(f32x4 *)(rowp + col * 4) = v0;
+            *(f32x4 *)(rowp + col * 4 + 16) = v1;
+        } else {
+            bf16x8 hi, lo;
+            split8(v0, v1, hi, lo);
+            *(bf16x8 *)(rowp + sp_off(col)) = hi;
+            *(bf16x8 *)(rowp + sp_off(col) + 64) = lo;
+        }
+    }
+}
+
+hipError_t launch_im2col3x3(int prec, const float *in, void *out, int batch, int h, int w, int C, int relu, hipStream_t s) {
+    if (C % 32 || batch <= 0 || h <= 0 || w <= 0) return hipErrorInvalidValue;
+    const size_t total = (size_t)batch * h * w * 9 * (C >> 3);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    const dim3 grid((unsigned)blocks), block(256);
+    if (prec == 0)
+        im2col3x3_kernel<1><<<grid, block, 0, s>>>(in, (char *)out, batch, h, w, C, relu);
+    else if (prec == 1)
+        im2col3x3_kernel<0><<<grid, block, 0, s>>>(in, (char *)out, batch, h, w, C, relu);
+    else
+        im2col3x3_kernel<2><<<grid, block, 0, s>>>(in, (char *)out, batch, h, w, C, relu);
+    return hipGetLastError();
+}

@@ -15,6 +15,7 @@ hipError_t launch_fold_split(const float *src, void *dst, int D, int C, int pp, 
 // sum over the channel axis of a (D, C, p, p) conv weight -> bf16 (D, p*p): grayscale fold.
 hipError_t launch_fold_cast_bf16(const float *src, bf16 *dst, int D, int C, int pp, hipStream_t s);
 hipError_t launch_fold_f32(const float *src, float *dst, int D, int C, int pp, hipStream_t s);
+hipError_t launch_im2col3x3(int prec, const float *in, void *out, int batch, int h, int w, int C, int relu, hipStream_t s);
 hipError_t launch_cls_rows(const float *cls, const float *pos, float *x, int batch, int n_tokens, int dim,
                            hipStream_t s);
 
@@ -24,8 +25,16 @@ hipError_t launch_cls_rows(const float *cls, const float *pos, float *x, int bat
 // ---- kernels_gemm.hip
 hipError_t launch_linear(int prec, const void *a, const void *w, const float *bias, const float *resid, void *out, int M,
                          int N, int K, int epilogue, hipStream_t s);
+// head_dim 64: q / k / vt are the attention kernels' operand copies (vt may be null when V is never read: want_v
+// false skips the V third). Any other head_dim (multiple of 8): q = k = vt = null, qkv_f32 (3,B,H,N,hd) is the output.
 hipError_t launch_qkv(int prec, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
-                      float *qkv_f32, int batch, int n_tokens, int n_pad, int heads, hipStream_t s);
+                      float *qkv_f32, int batch, int n_tokens, int n_pad, int heads, int head_dim, bool want_v,
+                      hipStream_t s);
+// Attention for heads that are not 64 wide (model.py:96-97: 3 heads x 128): fp32 FMA arithmetic on the fp32 qkv tensor.
+// ctx (activation type of `prec`, [B*N][H*hd]) / attn (B,H,N,N) / rows (B,H,n_rows,N-1) are optional outputs.
+hipError_t launch_attention_generic(int prec, const float *qkv, void *ctx, float *attn, const int32_t *query_rows,
+                                    int n_rows, float *rows, int batch, int n_tokens, int heads, int head_dim, float scale,
+                                    hipStream_t s);
 struct PatchArgs {
     const float *image;
     int64_t sb, sc, sy;

@@ -76,6 +76,7 @@ class Engine:
         self.cfg = OcmVitConfig(patch_size, in_chans, embed_dim, depth, num_heads, mlp_hidden, ln_eps, qk_scale,
                                 precision, 0)
         self.D, self.H, self.L, self.p = embed_dim, num_heads, depth, patch_size
+        self.hd = embed_dim // num_heads
         self._h = C.c_void_p(0)
         with torch.cuda.device(self.device):
             check(self.lib.ocm_vit_create(C.byref(self.cfg), C.byref(self._h)))
@@ -151,7 +152,7 @@ class Engine:
                 out["attn"] = torch.empty((n_last, B, H, n, n), **kw)
                 io.out_attn = out["attn"].data_ptr()
             if flags & OCM_OUT_QKV:
-                out["qkv"] = torch.empty((n_last, 3, B, H, n, 64), **kw)
+                out["qkv"] = torch.empty((n_last, 3, B, H, n, self.hd), **kw)
                 io.out_qkv = out["qkv"].data_ptr()
             if flags & OCM_OUT_TOKENS:
                 out["tokens"] = torch.empty((B, n, D), **kw)
@@ -219,7 +220,7 @@ class Engine:
                 (OCM_LAST_ATTN_ONLY if attn_only else 0)
         kw = dict(dtype=torch.float32, device=self.device)
         attn = torch.empty((B, self.H, n, n), **kw) if want_attn else None
-        qkv = torch.empty((3, B, self.H, n, 64), **kw) if want_qkv else None
+        qkv = torch.empty((3, B, self.H, n, self.hd), **kw) if want_qkv else None
         with torch.cuda.device(self.device):
             ws, wsb = self.workspace(B, n)
             check(self.lib.ocm_vit_block_forward(self._h, index, _p(xo), B, n, flags, _p(attn), _p(qkv), ws, wsb,

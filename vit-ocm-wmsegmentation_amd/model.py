@@ -164,22 +164,63 @@ class LinearProbing(nn.Module):
             nn.Conv2d(4 * s2, s2, kernel_size=3, padding=1), nn.PixelShuffle(encoder_stride))
         self.__dict__["_dec_cache"] = {}
 
+    def _two_layer(self, tokens):
+        """two_layer_decoder (model.py:154-166) in eval mode on the HIP path, token-major: im2col(3x3) + MFMA GEMM with
+        the BatchNorm (running statistics) folded into the first convolution's weights, ReLU applied while gathering the
+        second convolution's operand, PixelShuffle by the scatter kernel."""
+        conv1, bn, _, conv2, _ = self.two_layer_decoder
+        if bn.training:
+            raise NotImplementedError("the HIP decoder evaluates BatchNorm with its running statistics: call .eval()")
+        enc, dev, lib = self.encoder, tokens.device, _lib.load()
+        prec = _lib.PRECISIONS[enc._precision]
+        B, N, D = tokens.shape
+        hp = wp = int((N - 1) ** 0.5)
+        key = tuple((t.data_ptr(), t._version) for t in (conv1.weight, conv1.bias, bn.weight, bn.bias, bn.running_mean,
+                                                         bn.running_var, conv2.weight, conv2.bias)) + (prec,)
+        c = self._dec_cache
+        if c.get("key2") != key:
+            f32 = dict(device=dev, dtype=torch.float32)
+            g = (bn.weight.detach().to(**f32) / torch.sqrt(bn.running_var.detach().to(**f32) + bn.eps))
+            w1 = conv1.weight.detach().to(**f32) * g[:, None, None, None]
+            b1 = (conv1.bias.detach().to(**f32) - bn.running_mean.detach().to(**f32)) * g + bn.bias.detach().to(**f32)
+            # (O, C, 3, 3) -> (O, 3, 3, C): the K order of ocm_op_im2col3x3
+            w1 = w1.permute(0, 2, 3, 1).reshape(w1.shape[0], -1).contiguous()
+            w2 = conv2.weight.detach().to(**f32).permute(0, 2, 3, 1).reshape(conv2.out_channels, -1).contiguous()
+            c.update(key2=key, w1=to_operand(w1, prec), b1=b1.contiguous(), w2=to_operand(w2, prec),
+                     b2=conv2.bias.detach().to(**f32).contiguous())
+        M, mid, out_c = B * hp * wp, conv1.out_channels, conv2.out_channels
+        esz_t = {_lib.OCM_PREC_BF16: torch.bfloat16, _lib.OCM_PREC_FP32: torch.float32, _lib.OCM_PREC_BF16X3: torch.int32}[prec]
+        patches = tokens[:, 1:].contiguous()  # (B, hp*wp, D) fp32
+        out = torch.empty((B, 1, hp * self.encoder_stride, wp * self.encoder_stride), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            a1 = torch.empty((M, 9 * D), dtype=esz_t, device=dev)
+            _lib.check(lib.ocm_op_im2col3x3(prec, _p(patches), _p(a1), B, hp, wp, D, 0, _stream()))
+            y1 = torch.empty((M, mid), dtype=torch.float32, device=dev)
+            _lib.check(lib.ocm_op_linear(prec, _p(a1), _p(c["w1"]), _p(c["b1"]), None, _p(y1), M, mid, 9 * D,
+                                         _lib.OCM_EPI_BIAS_F32, _stream()))
+            a2 = torch.empty((M, 9 * mid), dtype=esz_t, device=dev)
+            _lib.check(lib.ocm_op_im2col3x3(prec, _p(y1), _p(a2), B, hp, wp, mid, 1, _stream()))  # ReLU on the way
+            y2 = torch.empty((M, out_c), dtype=torch.float32, device=dev)
+            _lib.check(lib.ocm_op_linear(prec, _p(a2), _p(c["w2"]), _p(c["b2"]), None, _p(y2), M, out_c, 9 * mid,
+                                         _lib.OCM_EPI_BIAS_F32, _stream()))
+            _lib.check(lib.ocm_op_pixel_shuffle(_p(y2), _p(out), B, hp, wp, out_c // self.encoder_stride ** 2,
+                                                self.encoder_stride, _stream()))
+        return out
+
     @torch.no_grad()
     def forward(self, x):
         _require_hip(x, "input")
-        if self.layer_num == 2:
-            # 3x3 conv + BatchNorm head: not on the hot path (SURVEY §8-f row 3 names the 1x1 head); it runs as the
-            # torch modules the reference builds, on the encoder's feature map
-            return self.two_layer_decoder(self.encoder(x))
         tokens = self.encoder._encode(x, tokens=True)
+        if self.layer_num == 2:
+            return self._two_layer(tokens)
         return _conv1x1_pixel_shuffle(self.encoder, tokens, self.one_layer_decoder[0], self.encoder_stride,
                                       self._dec_cache)
 
 
 def build_model(args):
-    """model.py:85-103. NOTE: the reference's MIM encoder is depth 4 with 3 heads of 128 channels; the engine's
-    attention kernels are built for 64-channel heads, so this configuration raises ValueError at its first
-    forward (documented gap; every DINO-shaped encoder — 64-channel heads — runs)."""
+    """model.py:85-103: the MIM pre-training encoder — depth 4, THREE heads of 128 channels. Heads that are not 64 wide
+    run the engine's generic fp32 attention kernel (kernels_attn.hip::attn_generic_kernel); everything else is the
+    same MFMA path as the DINO-shaped encoders."""
     return VisionTransformerForSimMIM(patch_size=args.MODEL.PATCH_SIZE, embed_dim=384, depth=4, num_heads=3,
                                       mlp_ratio=4, img_size=[args.DATA.IMG_SIZE], qkv_bias=True,
                                       norm_layer=partial(nn.LayerNorm, eps=1e-6), interpolate_encoding=True)

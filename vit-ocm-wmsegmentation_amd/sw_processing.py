@@ -152,6 +152,20 @@ class SlidingWindowAttention:
             slab = slab[:1]
         origins = sliding_window_origins(slab.shape[1], slab.shape[2], self.stride)
         T = origins.shape[0]
+        if T == 0:
+            raise ValueError(f"a {slab.shape[1]}x{slab.shape[2]} slab has no windows at stride {self.stride} "
+                             "(range(0, size - 2*stride, stride) is empty)")
+        if self.stride % 4:
+            raise ValueError("the window gather needs 16-byte aligned rows: stride must be a multiple of 4 pixels")
+        # Windows may reach past the slab (side not a multiple of the stride, or window > 3*stride): the reference's
+        # PIL crop zero-fills that part (sw_processing.py:157-160). The gather kernel reads origin + window unguarded,
+        # so the slab is zero-padded up to the farthest window edge, rows kept 16-byte aligned.
+        need_h = int(origins[:, 0].max()) + self.window
+        need_w = int(origins[:, 1].max()) + self.window
+        pad_h, pad_w = max(0, need_h - slab.shape[1]), max(0, need_w - slab.shape[2])
+        pad_w += (-(slab.shape[2] + pad_w)) % 4
+        if pad_h or pad_w or slab.shape[2] % 4:
+            slab = torch.nn.functional.pad(slab, (0, pad_w, 0, pad_h)).contiguous()
         world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank(self.group) if world > 1 else 0
         begin, end, share = shard_range(T, world, rank)

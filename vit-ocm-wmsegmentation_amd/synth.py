@@ -119,6 +119,22 @@ def synth_wrapper_params(embed_dim, stride, out_mult, *, seed=0):
     }
 
 
+def synth_two_layer_decoder_params(embed_dim, stride, *, seed=0):
+    """Parameters of LinearProbing.two_layer_decoder (model.py:154-166), keyed by their nn.Sequential state_dict names:
+    0 = Conv2d(D, 4 s^2, 3, padding=1), 1 = BatchNorm2d(4 s^2) (eval-mode statistics), 3 = Conv2d(4 s^2, s^2, 3, padding=1)."""
+    mid, out = 4 * stride * stride, stride * stride
+    return {
+        "0.weight": _uniform(seed, "dec2.0.weight", (mid, embed_dim, 3, 3), 1.0 / np.sqrt(9 * embed_dim)),
+        "0.bias": _uniform(seed, "dec2.0.bias", (mid,), 1.0 / np.sqrt(9 * embed_dim)),
+        "1.weight": 1.0 + _uniform(seed, "dec2.1.weight", (mid,), 0.3),
+        "1.bias": _uniform(seed, "dec2.1.bias", (mid,), 0.2),
+        "1.running_mean": _uniform(seed, "dec2.1.mean", (mid,), 0.3),
+        "1.running_var": 1.0 + _uniform(seed, "dec2.1.var", (mid,), 0.5),
+        "3.weight": _uniform(seed, "dec2.3.weight", (out, mid, 3, 3), 1.0 / np.sqrt(9 * mid)),
+        "3.bias": _uniform(seed, "dec2.3.bias", (out,), 1.0 / np.sqrt(9 * mid)),
+    }
+
+
 def synth_patch_mask(batch, side, *, seed=7, ratio=0.6):
     """SimMIM-style 0/1 patch mask (B, side, side) int64 with about `ratio` of the patches masked."""
     v = _rng(seed, "patch_mask").uniform(0, 1, size=(batch, side, side))
