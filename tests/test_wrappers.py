@@ -94,7 +94,7 @@ def test_build_functions_and_get_state_dict(tmp_path):
 
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 5e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 2e-4), ("bf16", 3e-2)])
 @pytest.mark.parametrize("name", sorted(WRAPPER_CASES))
 def test_wrappers_match_reference_fixtures(dev, name, precision, tol):
     """Encoders and decoders of model.py on the HIP path against the outputs of the reference's own classes.
@@ -133,7 +133,7 @@ def test_wrappers_match_reference_fixtures(dev, name, precision, tol):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 5e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 2e-5), ("bf16x3", 2e-4), ("bf16", 3e-2)])
 @pytest.mark.parametrize("name", sorted(WRAPPER_CASES))
 def test_two_layer_decoder_matches_reference_fixture(dev, name, precision, tol):
     """LinearProbing(layer_num=2) (model.py:154-171): 3x3 conv + BatchNorm(eval) + ReLU + 3x3 conv + PixelShuffle on
@@ -171,7 +171,7 @@ def test_reference_build_model_runs_with_128_channel_heads(dev):
     x = synth.synth_tiles(2, 64, seed=c["seed"] + 100)
     mask = synth.synth_patch_mask(2, 8, seed=c["seed"])
     g = load_golden("wrappers")
-    for precision, tol in (("bf16x3", 5e-5), ("fp32", 2e-5), ("bf16", 3e-2)):
+    for precision, tol in (("bf16x3", 2e-4), ("fp32", 2e-5), ("bf16", 3e-2)):
         z = enc.set_precision(precision)(x.to(dev), mask.to(dev))
         assert np.abs(z.cpu().numpy() - g["wrap_mim_hd128_fmap_masked"]).max() <= tol
     # per-head attention maps of 128-channel heads against the oracle
