@@ -288,6 +288,28 @@ int ocm_op_normalize_u8(const float *img, int64_t count, void *scratch, uint8_t 
 int32_t ocm_otsu_threshold(const uint64_t *hist256_host, int64_t count);
 int ocm_op_threshold_u8(const uint8_t *img, uint8_t *mask, int64_t count, int32_t thresh, void *stream);
 
+/* sw_processing.py:224-227 — the stitched image of the windows, as the reference builds it for threshold():
+ * concat_crops on the uint8 RGB windows (float64 blend, TRUNCATED into the uint8 overlap array at every fold), then
+ * PIL .convert("L"). `image`: the float slab planes (x = u / 255 as ToTensor made them; 1 or 3 planes, strides in
+ * elements), height x width pixels; windows that reach past the slab are zero-filled (PIL crop). out: (S,S) uint8,
+ * S = window + (n-1)*stride; hist256 optional. */
+int ocm_op_stitch_image_u8(const float *image, int64_t stride_c, int64_t stride_y, int32_t chans, int32_t height,
+                           int32_t width, uint8_t *out, const double *ramp, int32_t n, int32_t window, int32_t stride,
+                           uint64_t *hist256, void *stream);
+/* sw_processing.py:42-48 — attention = min_max_normalize(heat); result = (img * attention / max(attention)).astype(uint8)
+ * (float32 arithmetic, truncation) and att_u8 = (attention * 255).astype(uint8), with both 256-bin histograms.
+ * scratch: >= 2048 bytes. */
+int ocm_op_weighted_u8(const float *heat, const uint8_t *img, int64_t count, void *scratch, uint8_t *result,
+                       uint8_t *att_u8, uint64_t *hist_result, uint64_t *hist_att, void *stream);
+
+/* eval.py:144,158 — scipy.ndimage.median_filter(map, size): size x size footprint, mode "reflect", upper median.
+ * (T,h,w) fp32 -> (T,h,w); src != dst. Pinned against scipy (tests/golden/median.npz). */
+int ocm_op_median_filter(const float *src, float *dst, int32_t tiles, int32_t h, int32_t w, int32_t size, void *stream);
+/* eval.py:169, sw_processing.py:255 — cv2.resize(map, (w/f, h/f)) (INTER_LINEAR) for an integer factor: the two
+ * centre pixels averaged per axis in float32 (cv2: parity unpinned). (T,h,w) -> (T,h/f,w/f). */
+int ocm_op_downscale_centre(const float *src, float *dst, int32_t tiles, int32_t h, int32_t w, int32_t factor,
+                            void *stream);
+
 /* ---- eval.py's per-image mask chain (eval.py:126-171, utils.py:55-115 threshold()) ---- */
 /* eval.py:142 — np.mean(attention_response, axis=0): rows (T,H,n_rows,P) -> maps (T,P), sequential fp32. */
 int ocm_op_head_mean(const float *rows, float *maps, int32_t tiles, int32_t heads, int32_t n_rows,

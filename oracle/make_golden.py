@@ -155,6 +155,23 @@ def run_helpers():
         assert stitched.shape == (384 + (n - 1) * 128,) * 2 and np.array_equal(stitched, ostitched)
         out[f"stitch_{n}_seed"] = np.int64(seed)
         out[f"stitch_{n}"] = stitched.astype(np.float32)
+    # the same stitcher on uint8 RGB windows (what sw_processing.py:224-227 feeds it): float64 blends truncated into the
+    # uint8 overlap arrays. Windows cut from one image (the real use) and independent random windows (a stricter pin).
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (3 * 32 + 96 - 32, 3 * 32 + 96 - 32), dtype=np.uint8)  # 160 x 160, window 96, stride 32
+    rgb = np.repeat(img[:, :, None], 3, axis=2)
+    crops = ref_s["sliding_window"](Image.fromarray(rgb, mode="RGB"), 32, 96)
+    assert len(crops) == 9 and crops[0].shape == (96, 96, 3) and crops[0].dtype == np.uint8
+    stitched = ref_s["concat_crops"](crops, 32, 96)
+    gray = np.asarray(Image.fromarray(stitched).convert("RGB").convert("L"))
+    assert np.array_equal(gray, O.stitched_gray_image(img, 32, 96))
+    out["stitch_u8_seed"] = np.int64(9)
+    out["stitch_u8_gray"] = gray
+    rnd = [rng.integers(0, 256, (96, 96, 3), dtype=np.uint8) for _ in range(9)]
+    srnd = ref_s["concat_crops"](rnd, 32, 96)
+    assert np.array_equal(srnd, O.concat_crops(rnd, 32, 96))
+    out["stitch_u8_random"] = np.asarray(Image.fromarray(srnd).convert("L"))
+    assert np.array_equal(out["stitch_u8_random"], O.pil_rgb_to_l(srnd))
     path = os.path.join(GOLD, "helpers.npz")
     np.savez_compressed(path, **out)
     print(f"helpers            compute_attention / sliding_window / concat_crops pinned -> {os.path.relpath(path, ROOT)} "
@@ -243,6 +260,8 @@ def main():
     torch.set_num_threads(8)
     if "--only-wrappers" in sys.argv:
         return run_wrappers()
+    if "--only-helpers" in sys.argv:
+        return run_helpers()
     run_helpers()
     run_wrappers()
     for name, case in CASES.items():

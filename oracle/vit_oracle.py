@@ -187,8 +187,8 @@ def blend_overlap(a, b, axis):
     (weights are float64 there; the sum is cast back to the crops' dtype on assignment)."""
     n = a.shape[axis]
     w = np.linspace(1, 0, n)
-    w = w[:, None] if axis == 0 else w[None, :]
-    return (a * w + b * (1 - w)).astype(a.dtype)
+    w = w.reshape([n if d == axis else 1 for d in range(a.ndim)])  # (h, w) maps or (h, w, 3) uint8 RGB windows
+    return (a * w + b * (1 - w)).astype(a.dtype)  # uint8 windows: float64 blend, TRUNCATED on assignment
 
 
 def concat_crops(crops, stride, window):
@@ -245,6 +245,90 @@ def bilinear_upsample(maps, scale):
     return F.interpolate(t, scale_factor=scale, mode="bilinear", align_corners=False)[:, 0].numpy()
 
 
+def pil_rgb_to_l(rgb_u8):
+    """PIL Image.convert("L") of an RGB uint8 array (h, w, 3): (19595 R + 38470 G + 7471 B + 0x8000) >> 16."""
+    a = np.asarray(rgb_u8).astype(np.uint32)
+    return ((19595 * a[..., 0] + 38470 * a[..., 1] + 7471 * a[..., 2] + 0x8000) >> 16).astype(np.uint8)
+
+
+def stitched_gray_image(image_u8, stride, window):
+    """sw_processing.py:224-227: `output_image = concat_crops(sliding_window(img), stride, window)` on the uint8 RGB
+    windows (np.array(PIL crop)), then Image.fromarray(...).convert("RGB").convert("L") as threshold() receives it.
+    image_u8: (H, W) or (H, W, 3) uint8. Windows past the image edge are PIL crop's zeros."""
+    a = np.asarray(image_u8, dtype=np.uint8)
+    rgb = a if a.ndim == 3 else np.repeat(a[:, :, None], 3, axis=2)
+    H, W = rgb.shape[:2]
+    origins = sliding_window_origins(H, W, stride)
+    need_h = max(y for y, _ in origins) + window
+    need_w = max(x for _, x in origins) + window
+    pad = np.zeros((max(H, need_h), max(W, need_w), 3), np.uint8)
+    pad[:H, :W] = rgb
+    crops = [pad[y:y + window, x:x + window] for y, x in origins]
+    return pil_rgb_to_l(concat_crops(crops, stride, window))
+
+
+def skimage_otsu_level(img_u8):
+    """skimage.filters.threshold_otsu (scikit-image 0.19.3, the reference's pin; an un-vendored dependency that is
+    not installable here: PARITY UNPINNED) for a uint8 image: integer histogram over [min, max], float64 class
+    weights / means, first maximum of the between-class variance; pixels > level are foreground."""
+    img = np.asarray(img_u8, dtype=np.uint8)
+    if img.min() == img.max():
+        return int(img.flat[0])
+    lo, hi = int(img.min()), int(img.max())
+    counts = np.bincount(img.ravel(), minlength=256)[lo:hi + 1].astype(np.float64)
+    centers = np.arange(lo, hi + 1)
+    weight1 = np.cumsum(counts)
+    weight2 = np.cumsum(counts[::-1])[::-1]
+    mean1 = np.cumsum(counts * centers) / weight1
+    mean2 = (np.cumsum((counts * centers)[::-1]) / weight2[::-1])[::-1]
+    variance12 = weight1[:-1] * weight2[1:] * (mean1[:-1] - mean2[1:]) ** 2
+    return int(centers[int(np.argmax(variance12))])
+
+
+def sw_threshold_masks(img_u8, heat):
+    """threshold() of sw_processing.py:37-81 (save=False): returns (th, th2, th3), (levels), result.
+      attention = min_max_normalize(heat);  result = (img * attention / np.max(attention)).astype(uint8)   :42-46
+      th  = cv2 Otsu mask of result  :53      th2 = img > skimage Otsu(img)  :55-58      th3 = cv2 Otsu of attention*255  :60"""
+    heat = np.asarray(heat, dtype=np.float32)
+    mn, mx = heat.min(), heat.max()
+    att = heat if mx == mn else (heat - mn) / (mx - mn)
+    img = np.asarray(img_u8, dtype=np.uint8)
+    result = (img * att / np.max(att)).astype(np.uint8)  # uint8 * float32 -> float32
+    att_u8 = (att * 255).astype(np.uint8)
+    l1, l2, l3 = otsu_level(result), skimage_otsu_level(img), otsu_level(att_u8)
+    th = np.where(result > l1, 255, 0).astype(np.uint8)
+    th2 = (img > l2).astype(np.uint8) * 255
+    th3 = np.where(att_u8 > l3, 255, 0).astype(np.uint8)
+    return (th, th2, th3), (l1, l2, l3), result
+
+
+def median_filter(maps, size):
+    """scipy.ndimage.median_filter(map, size=size) of eval.py:144,158 for (T, h, w) maps: size x size footprint, mode
+    "reflect", origin 0, rank (size*size)//2. Pinned against scipy (tests/golden/median.npz)."""
+    maps = np.asarray(maps, dtype=np.float32)
+    if size == 1:
+        return maps.copy()
+    lo, hi = size // 2, size - 1 - size // 2
+    out = np.empty_like(maps)
+    for t in range(maps.shape[0]):
+        p = np.pad(maps[t], ((lo, hi), (lo, hi)), mode="symmetric")  # numpy "symmetric" == scipy "reflect"
+        win = np.stack([p[dy:dy + maps.shape[1], dx:dx + maps.shape[2]] for dy in range(size) for dx in range(size)], 0)
+        out[t] = np.sort(win, axis=0)[(size * size) // 2]
+    return out
+
+
+def cv2_downscale(maps, f):
+    """cv2.resize(map, (w // f, h // f)) (INTER_LINEAR, eval.py:169, sw_processing.py:255) for an integer factor on
+    (T, h, w) float32 maps: centre-pair average per axis in float32, horizontal pass first (PARITY UNPINNED: cv2)."""
+    m = np.asarray(maps, dtype=np.float32)
+    if f % 2:
+        return m[:, f // 2::f, f // 2::f].copy()
+    c = f // 2 - 1
+    half = np.float32(0.5)
+    rows = m[:, :, c::f] * half + m[:, :, c + 1::f] * half
+    return rows[:, c::f] * half + rows[:, c + 1::f] * half
+
+
 def otsu_level(img_u8):
     """cv2.threshold(..., THRESH_OTSU) level: OpenCV 4.6 getThreshVal_Otsu_8u restated (PARITY UNPINNED)."""
     hist = np.bincount(np.asarray(img_u8, dtype=np.uint8).ravel(), minlength=256).astype(np.float64)
@@ -291,16 +375,38 @@ def to_pil_gray_u8(img_chw):
     return ((19595 * a[0] + 38470 * a[1] + 7471 * a[2] + 0x8000) >> 16).astype(np.uint8)
 
 
-def eval_average_attention(cls_rows, hf, wf, patch_size):
-    """eval.py:136-144,164-166 for one image: cls_rows (H, hf*wf) = attentions[0][0, :, 0, 1:] ->
-    nearest x p -> np.mean over heads -> median_filter(size=1) (identity) -> cv2.resize down by p (returns
-    the hf x wf block values) -> cv2.resize INTER_LINEAR up to the image size."""
+def head_mean_upsampled(cls_rows, hf, wf, patch_size, median=1):
+    """eval.py:136-144 for one forward: cls_rows (H, hf*wf) = attentions[0][0, :, 0, 1:] -> nearest x p
+    (compute_attention) -> np.mean over heads (sequential float32) -> scipy median_filter(size=median).
+    Returns the (hf*p, wf*p) float32 map."""
     rows = np.asarray(cls_rows, dtype=np.float32)
     s = rows[0].copy()
     for h in range(1, rows.shape[0]):
         s = s + rows[h]
-    avg = (s / np.float32(rows.shape[0])).astype(np.float32).reshape(1, hf, wf)
-    return bilinear_upsample(avg, patch_size)[0]
+    avg = (s / np.float32(rows.shape[0])).astype(np.float32).reshape(hf, wf)
+    up = np.repeat(np.repeat(avg, patch_size, axis=0), patch_size, axis=1)
+    return median_filter(up[None], int(median))[0]
+
+
+def eval_average_attention(cls_rows, hf, wf, patch_size, median=1):
+    """eval.py:136-144,169-171 for one image (--crop 1): head_mean_upsampled -> cv2.resize down by p -> cv2.resize
+    INTER_LINEAR up to the image size."""
+    up = head_mean_upsampled(cls_rows, hf, wf, patch_size, median)
+    return bilinear_upsample(cv2_downscale(up[None], patch_size), patch_size)[0]
+
+
+def plain_concat_crops(crops):
+    """utils.py:304-317 concat_crops(crops): the sqrt(n) x sqrt(n) row-major grid of equal tiles, no blending."""
+    n = int(np.sqrt(len(crops)))
+    return np.concatenate([np.concatenate([crops[i * n + j] for j in range(n)], axis=1) for i in range(n)], axis=0)
+
+
+def eval_crops_average_attention(cls_rows_per_crop, hf, wf, patch_size, median=1):
+    """eval.py:146-171 (--crop 4 / 16) for one image: per crop head_mean_upsampled (median filter per crop), the maps
+    tiled by utils.concat_crops, then the same down / up resize as the single-crop path."""
+    maps = [head_mean_upsampled(r, hf, wf, patch_size, median) for r in cls_rows_per_crop]
+    full = plain_concat_crops(maps)
+    return bilinear_upsample(cv2_downscale(full[None], patch_size), patch_size)[0]
 
 
 def threshold_masks(img_u8, attention):

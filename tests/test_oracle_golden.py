@@ -97,3 +97,54 @@ def test_oracle_threshold_chain_properties():
     assert 40 <= l2 < 200 and np.array_equal(th2, np.where(img > l2, 255, 0))
     assert np.array_equal(result, ((img / 2) * 0.6 + (127 / 2) * 0.4).astype(np.uint8))  # flat map: 0.5*255 -> 127
     assert set(np.unique(th3)) <= {0, 255}
+
+
+def test_median_filter_restatement_equals_scipy_fixture():
+    """oracle.median_filter against outputs of the real scipy.ndimage.median_filter (eval.py:144,158) — fixture written by
+    oracle/make_golden_median.py; when scipy is importable where the tests run, against scipy itself too."""
+    import numpy as np
+    from oracle import vit_oracle as O
+    from oracle.make_golden_median import SIZES, inputs
+    from tests.helpers import load_golden
+    gold = load_golden("median")
+    x = inputs(int(gold["seed"]))
+    for k in SIZES:
+        assert np.array_equal(O.median_filter(x, k), gold[f"size{k}"]), k
+    try:
+        from scipy.ndimage import median_filter
+    except ImportError:
+        return
+    for k in (2, 3, 6):
+        assert np.array_equal(O.median_filter(x[:1], k)[0], median_filter(x[0], size=k))
+
+
+def test_uint8_stitcher_restatement_equals_reference_fixture():
+    """oracle.stitched_gray_image / concat_crops on uint8 RGB windows against the reference's own sliding_window +
+    concat_crops + PIL convert (helpers.npz: stitch_u8_*)."""
+    import numpy as np
+    from oracle import vit_oracle as O
+    from tests.helpers import load_golden
+    gold = load_golden("helpers")
+    rng = np.random.default_rng(int(gold["stitch_u8_seed"]))
+    img = rng.integers(0, 256, (160, 160), dtype=np.uint8)
+    assert np.array_equal(O.stitched_gray_image(img, 32, 96), gold["stitch_u8_gray"])
+    rnd = [rng.integers(0, 256, (96, 96, 3), dtype=np.uint8) for _ in range(9)]
+    assert np.array_equal(O.pil_rgb_to_l(O.concat_crops(rnd, 32, 96)), gold["stitch_u8_random"])
+
+
+def test_post_chain_restatements_are_self_consistent():
+    """cv2 / skimage steps are restated (parity unpinned): properties that must hold whatever the library version."""
+    import numpy as np
+    from oracle import vit_oracle as O
+    rng = np.random.default_rng(2)
+    small = rng.random((3, 6, 5), dtype=np.float32)
+    for p in (8, 16):
+        up = np.repeat(np.repeat(small, p, 1), p, 2)
+        assert np.array_equal(O.cv2_downscale(up, p), small)      # block-constant map: the centre average is the value
+        assert np.array_equal(O.cv2_downscale(np.repeat(np.repeat(small, 16, 1), 16, 2), 8), np.repeat(np.repeat(small, 2, 1), 2, 2))
+    img = np.concatenate([rng.integers(40, 90, 5000), rng.integers(150, 220, 5000)]).astype(np.uint8).reshape(100, 100)
+    lvl = O.skimage_otsu_level(img)
+    assert 89 <= lvl < 150 and abs(lvl - O.otsu_level(img)) <= 1  # both maximise the same between-class variance
+    assert O.skimage_otsu_level(np.full((4, 4), 7, np.uint8)) == 7
+    tiles = [np.full((2, 3), i, np.float32) for i in range(4)]
+    assert np.array_equal(O.plain_concat_crops(tiles), np.array([[0, 0, 0, 1, 1, 1]] * 2 + [[2, 2, 2, 3, 3, 3]] * 2, np.float32))

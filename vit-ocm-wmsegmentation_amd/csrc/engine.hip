@@ -742,6 +742,44 @@ extern "C" int ocm_op_pixel_shuffle(const float *lin, float *out, int32_t batch,
     return OCM_OK;
 }
 
+extern "C" int ocm_op_stitch_image_u8(const float *image, int64_t stride_c, int64_t stride_y, int32_t chans, int32_t height,
+                                      int32_t width, uint8_t *out, const double *ramp, int32_t n, int32_t window,
+                                      int32_t stride, uint64_t *hist256, void *stream) {
+    if (!image || !out || !ramp) return fail(OCM_EINVAL, "null argument");
+    if (chans != 1 && chans != 3) return fail(OCM_EINVAL, "stitch_image_u8 takes 1 or 3 planes");
+    if (n <= 0 || stride <= 0 || window <= stride || window > 3 * stride || height <= 0 || width <= 0)
+        return fail(OCM_EINVAL, "stitch needs stride < window <= 3*stride (got window %d stride %d)", window, stride);
+    HIP_TRY(launch_stitch_image_u8(image, stride_c, stride_y, chans, height, width, out, ramp, n, window, stride,
+                                   (unsigned long long *)hist256, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_weighted_u8(const float *heat, const uint8_t *img, int64_t count, void *scratch, uint8_t *result,
+                                  uint8_t *att_u8, uint64_t *hist_result, uint64_t *hist_att, void *stream) {
+    if (!heat || !img || !scratch || !result || !att_u8 || !hist_result || !hist_att) return fail(OCM_EINVAL, "null argument");
+    if (count <= 0) return fail(OCM_EINVAL, "bad count");
+    HIP_TRY(launch_weighted_u8(heat, img, (size_t)count, (float *)scratch, result, att_u8, (unsigned long long *)hist_result,
+                               (unsigned long long *)hist_att, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_median_filter(const float *src, float *dst, int32_t tiles, int32_t h, int32_t w, int32_t size,
+                                    void *stream) {
+    if (!src || !dst || src == dst) return fail(OCM_EINVAL, "null or aliased argument");
+    if (tiles <= 0 || h <= 0 || w <= 0 || size < 1 || size > 15) return fail(OCM_EINVAL, "bad shape / size (1..15)");
+    HIP_TRY(launch_median_filter(src, dst, tiles, h, w, size, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_downscale_centre(const float *src, float *dst, int32_t tiles, int32_t h, int32_t w, int32_t factor,
+                                       void *stream) {
+    if (!src || !dst) return fail(OCM_EINVAL, "null argument");
+    if (tiles <= 0 || h <= 0 || w <= 0 || factor < 1 || h % factor || w % factor)
+        return fail(OCM_EINVAL, "bad shape: %dx%d is not a multiple of the factor %d", h, w, factor);
+    HIP_TRY(launch_downscale_centre(src, dst, tiles, h, w, factor, (hipStream_t)stream));
+    return OCM_OK;
+}
+
 extern "C" int ocm_op_im2col3x3(int32_t precision, const float *in, void *out, int32_t batch, int32_t h, int32_t w,
                                 int32_t channels, int32_t relu, void *stream) {
     int pc = 0, rc = prec_of(precision, &pc);

@@ -287,3 +287,207 @@ hipError_t launch_blend_u8(const uint8_t *img, const uint8_t *att, size_t count,
     blend_u8_kernel<<<dim3(1024), dim3(256), 0, s>>>(img, att, count, alpha, one_minus_alpha, out, hist256);
     return hipGetLastError();
 }
+
+// ---- sw_processing.py:224-227: the stitched image the masks th / th2 are computed on ------------------------------
+// output_image = concat_crops(cropped_images, ...) on the uint8 RGB windows, then Image.fromarray(...).convert("L").
+// Same left fold as stitch_kernel, but numpy evaluates `uint8 * float64 + uint8 * float64` in float64 and the
+// assignment into the uint8 overlap array TRUNCATES (:136-149) — a blended pixel can therefore come out one below the
+// two (identical) values it blends. The windows are read in place from the float slab (what ToTensor made of the uint8
+// image: x = u / 255, so u = rint(x * 255)); window pixels outside the slab are PIL crop's zeros.
+__device__ __forceinline__ int slab_u8(const float *__restrict__ plane, int64_t sy, int H, int W, int y, int x) {
+    if (y >= H || x >= W) return 0;
+    return (int)rintf(plane[(int64_t)y * sy + x] * 255.0f);
+}
+__device__ __forceinline__ int blend_trunc(int a, int b, double w) {
+    const double l = (double)a * w, r = (double)b * (1.0 - w);
+    return (int)(unsigned char)(int)(l + r);
+}
+__device__ __forceinline__ int strip_value_u8(const float *__restrict__ plane, int64_t sy, int H, int W,
+                                              const double *__restrict__ ramp, int n, int window, int stride, int row_i,
+                                              int r, int X) {
+    int j0 = max((X - window + stride) / stride, 0);
+    while (X - stride * j0 >= window) ++j0;
+    const int j1 = min(X / stride, n - 1);
+    const int y = row_i * stride + r;
+    int v = slab_u8(plane, sy, H, W, y, j0 * stride + (X - stride * j0));
+    for (int j = j0 + 1; j <= j1; ++j) {
+        const int c = X - stride * j;
+        v = blend_trunc(v, slab_u8(plane, sy, H, W, y, j * stride + c), ramp[c]);
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void stitch_image_u8_kernel(const float *__restrict__ image, int64_t sc, int64_t sy,
+                                                              int chans, int H, int W, uint8_t *__restrict__ out,
+                                                              const double *__restrict__ ramp, int n, int window,
+                                                              int stride, unsigned long long *hist) {
+    __shared__ unsigned int lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    const int S = window + (n - 1) * stride;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < S * S; i += gridDim.x * 256) {
+        const int Y = i / S, X = i - Y * S;
+        int i0 = max((Y - window + stride) / stride, 0);
+        while (Y - stride * i0 >= window) ++i0;
+        const int i1 = min(Y / stride, n - 1);
+        unsigned int ch[3];
+        for (int c = 0; c < chans; ++c) {
+            const float *plane = image + c * sc;
+            int v = strip_value_u8(plane, sy, H, W, ramp, n, window, stride, i0, Y - stride * i0, X);
+            for (int ii = i0 + 1; ii <= i1; ++ii) {
+                const int r = Y - stride * ii;
+                v = blend_trunc(v, strip_value_u8(plane, sy, H, W, ramp, n, window, stride, ii, r, X), ramp[r]);
+            }
+            ch[c] = (unsigned int)v;
+        }
+        // .convert("RGB").convert("L"): PIL's (19595 R + 38470 G + 7471 B + 0x8000) >> 16 (grey planes: identity)
+        const unsigned int u = chans == 1 ? ch[0] : (19595u * ch[0] + 38470u * ch[1] + 7471u * ch[2] + 0x8000u) >> 16;
+        out[i] = (uint8_t)u;
+        if (hist) atomicAdd(&lh[u], 1u);
+    }
+    __syncthreads();
+    if (hist && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+hipError_t launch_stitch_image_u8(const float *image, int64_t sc, int64_t sy, int chans, int H, int W, uint8_t *out,
+                                  const double *ramp, int n, int window, int stride, unsigned long long *hist256,
+                                  hipStream_t s) {
+    if (hist256) {
+        hipError_t e = hipMemsetAsync(hist256, 0, 256 * sizeof(unsigned long long), s);
+        if (e != hipSuccess) return e;
+    }
+    const long S = window + (long)(n - 1) * stride;
+    long blocks = (S * S + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    stitch_image_u8_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(image, sc, sy, chans, H, W, out, ramp, n, window,
+                                                                         stride, hist256);
+    return hipGetLastError();
+}
+
+// ---- sw_processing.py:43-46: result = (img * attention / np.max(attention)).astype(np.uint8) with attention =
+// min_max_normalize(heat): uint8 * float32 -> float32 products, float32 division by the normalised map's maximum
+// (1.0 unless the map is flat, then the map's own value), truncation. One pass also emits attention * 255 as uint8
+// (:47-48) and both histograms.
+__global__ __launch_bounds__(256) void weighted_u8_kernel(const float *__restrict__ heat, const uint8_t *__restrict__ img,
+                                                          size_t count, const float *__restrict__ part, int nparts,
+                                                          uint8_t *__restrict__ result, uint8_t *__restrict__ att_u8,
+                                                          unsigned long long *hist_res, unsigned long long *hist_att) {
+    __shared__ unsigned int lr[256], la[256];
+    __shared__ float mm[2];
+    lr[threadIdx.x] = 0;
+    la[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        float mn = INFINITY, mx = -INFINITY;
+        for (int i = 0; i < nparts; ++i) {
+            mn = fminf(mn, part[2 * i]);
+            mx = fmaxf(mx, part[2 * i + 1]);
+        }
+        mm[0] = mn;
+        mm[1] = mx;
+    }
+    __syncthreads();
+    const float mn = mm[0], mx = mm[1], range = mx - mn;
+    const float amax = mx != mn ? (mx - mn) / range : mx;  // np.max of the normalised map
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        float a = heat[i];
+        if (mx != mn) a = (a - mn) / range;
+        const float prod = (float)img[i] * a;
+        const uint8_t r = (uint8_t)(int)(prod / amax);
+        const uint8_t u = (uint8_t)(int)(a * 255.0f);
+        result[i] = r;
+        att_u8[i] = u;
+        atomicAdd(&lr[r], 1u);
+        atomicAdd(&la[u], 1u);
+    }
+    __syncthreads();
+    if (lr[threadIdx.x]) atomicAdd(&hist_res[threadIdx.x], (unsigned long long)lr[threadIdx.x]);
+    if (la[threadIdx.x]) atomicAdd(&hist_att[threadIdx.x], (unsigned long long)la[threadIdx.x]);
+}
+
+hipError_t launch_weighted_u8(const float *heat, const uint8_t *img, size_t count, float *part /*[2*256]*/,
+                              uint8_t *result, uint8_t *att_u8, unsigned long long *hist_res, unsigned long long *hist_att,
+                              hipStream_t s) {
+    hipError_t e = hipMemsetAsync(hist_res, 0, 256 * sizeof(unsigned long long), s);
+    if (e == hipSuccess) e = hipMemsetAsync(hist_att, 0, 256 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    minmax_partial_kernel<<<dim3(256), dim3(256), 0, s>>>(heat, count, part);
+    weighted_u8_kernel<<<dim3(1024), dim3(256), 0, s>>>(heat, img, count, part, 256, result, att_u8, hist_res, hist_att);
+    return hipGetLastError();
+}
+
+// ---- eval.py:144,158: scipy.ndimage.median_filter(map, size=k) — k x k footprint, mode "reflect" (d c b a | a b c d |
+// d c b a), origin 0 (window offsets -k/2 .. k-1-k/2), the element of rank (k*k)/2 of the sorted window. Pinned
+// against scipy itself (tests/golden/median.npz, oracle/make_golden_median.py). Selection by counting: a window value
+// whose number of smaller elements (ties broken by position) equals the rank is the answer; no per-thread arrays.
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    // scipy "reflect": ... 1 0 | 0 1 2 ... n-1 | n-1 n-2 ...   (period 2n)
+    const int p = 2 * n;
+    i = ((i % p) + p) % p;
+    return i < n ? i : p - 1 - i;
+}
+
+__global__ __launch_bounds__(256) void median_filter_kernel(const float *__restrict__ src, float *__restrict__ dst, int h,
+                                                            int w, int k, size_t total) {
+    const int n = k * k, rank = n / 2, lo = -(k / 2);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % w);
+        const size_t t = i / w;
+        const int y = (int)(t % h);
+        const float *img = src + (t / h) * (size_t)h * w;
+        float ans = 0.f;
+        for (int a = 0; a < n; ++a) {
+            const float va = img[(size_t)reflect_idx(y + lo + a / k, h) * w + reflect_idx(x + lo + a % k, w)];
+            int less = 0;
+            for (int b = 0; b < n; ++b) {
+                const float vb = img[(size_t)reflect_idx(y + lo + b / k, h) * w + reflect_idx(x + lo + b % k, w)];
+                less += (vb < va) || (vb == va && b < a);
+            }
+            if (less == rank) {
+                ans = va;
+                break;
+            }
+        }
+        dst[i] = ans;
+    }
+}
+
+hipError_t launch_median_filter(const float *src, float *dst, int tiles, int h, int w, int k, hipStream_t s) {
+    if (tiles <= 0 || h <= 0 || w <= 0 || k < 1 || k > 15) return hipErrorInvalidValue;
+    const size_t total = (size_t)tiles * h * w;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    median_filter_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(src, dst, h, w, k, total);
+    return hipGetLastError();
+}
+
+// ---- eval.py:169 / sw_processing.py:255: cv2.resize(map, (W / f, H / f)) (default INTER_LINEAR) for an even integer
+// factor f: the sample point (x + 0.5) * f - 0.5 sits midway between source pixels f*x + f/2 - 1 and f*x + f/2, so
+// the result is the horizontal pass 0.5 * a + 0.5 * b followed by the same vertically, in float32 (cv2's
+// hresize / vresize order; cv2 is an un-vendored dependency: parity unpinned). Odd f: the centre pixel.
+__global__ __launch_bounds__(256) void downscale_centre_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                               int h, int w, int f, size_t total) {
+    const int ho = h / f, wo = w / f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int x = (int)(i % wo);
+        const size_t t = i / wo;
+        const int y = (int)(t % ho);
+        const float *img = src + (t / ho) * (size_t)h * w;
+        if (f & 1) {
+            dst[i] = img[(size_t)(y * f + f / 2) * w + x * f + f / 2];
+        } else {
+            const int y0 = y * f + f / 2 - 1, x0 = x * f + f / 2 - 1;
+            const float r0 = img[(size_t)y0 * w + x0] * 0.5f + img[(size_t)y0 * w + x0 + 1] * 0.5f;
+            const float r1 = img[(size_t)(y0 + 1) * w + x0] * 0.5f + img[(size_t)(y0 + 1) * w + x0 + 1] * 0.5f;
+            dst[i] = r0 * 0.5f + r1 * 0.5f;
+        }
+    }
+}
+
+hipError_t launch_downscale_centre(const float *src, float *dst, int tiles, int h, int w, int f, hipStream_t s) {
+    if (tiles <= 0 || h <= 0 || w <= 0 || f < 1 || h % f || w % f) return hipErrorInvalidValue;
+    const size_t total = (size_t)tiles * (h / f) * (w / f);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    downscale_centre_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(src, dst, h, w, f, total);
+    return hipGetLastError();
+}

@@ -75,6 +75,14 @@ hipError_t launch_image_to_gray_u8(const float *img, int64_t stride_c, int chans
 hipError_t launch_blend_u8(const uint8_t *img, const uint8_t *att, size_t count, double alpha, double one_minus_alpha,
                            uint8_t *out, unsigned long long *hist256, hipStream_t s);
 
+hipError_t launch_stitch_image_u8(const float *image, int64_t sc, int64_t sy, int chans, int H, int W, uint8_t *out,
+                                  const double *ramp, int n, int window, int stride, unsigned long long *hist256,
+                                  hipStream_t s);
+hipError_t launch_weighted_u8(const float *heat, const uint8_t *img, size_t count, float *part, uint8_t *result,
+                              uint8_t *att_u8, unsigned long long *hist_res, unsigned long long *hist_att, hipStream_t s);
+hipError_t launch_median_filter(const float *src, float *dst, int tiles, int h, int w, int k, hipStream_t s);
+hipError_t launch_downscale_centre(const float *src, float *dst, int tiles, int h, int w, int f, hipStream_t s);
+
 static inline int ocm_round_up(int v, int m) { return (v + m - 1) / m * m; }
 // padded token count of the q / k / V^T buffers: the key axis of V^T is a contraction axis, so split pairs need whole
 // groups of 32 keys

@@ -60,11 +60,15 @@ def _dev_call(t):
     return torch.cuda.device(t.device)
 
 
-def postprocess_windows(rows, hf, wf, scale):
+def postprocess_windows(rows, hf, wf, patch_size):
     """rows: (T, heads, n_rows, hf*wf) CLS-row maps on a HIP device. Per window, as the tile loop of
-    sw_processing.py:245,253-257 does on the CPU: head mean -> (v - min) / (max - min) * 255 ->
-    (cv2.resize down by 8 of the nearest-upsampled map = the hf x wf map itself) -> cv2.resize
-    INTER_LINEAR up by `scale`. Returns (T, hf*scale, wf*scale) fp32."""
+    sw_processing.py:245,253-257 does on the CPU: head mean -> (v - min) / (max - min) * 255 -> cv2.resize DOWN BY 8
+    of the nearest-upsampled (x patch_size) map -> cv2.resize INTER_LINEAR UP BY 8 (the reference hard-codes the 8s).
+    For patch 8 the down-scaled map is the hf x wf map itself; for patch 16 every down-scaled pixel samples inside
+    one 16 x 16 block, so it is the hf x wf map nearest-upsampled by 2. Returns (T, hf*p, wf*p) fp32."""
+    if patch_size % 8:
+        raise ValueError(f"the reference's //8 then *8 resize needs a patch size that is a multiple of 8, got {patch_size}")
+    rep, scale = patch_size // 8, 8
     _require = rows.is_cuda and rows.dtype == torch.float32
     if not _require:
         raise RuntimeError("postprocess_windows needs a float32 tensor on a HIP device (no CPU fallback)")
@@ -74,12 +78,14 @@ def postprocess_windows(rows, hf, wf, scale):
         raise ValueError(f"rows have {P} pixels, expected {hf}x{wf}")
     lib = _lib.load()
     small = torch.empty((T, hf, wf), dtype=torch.float32, device=rows.device)
-    big = torch.empty((T, hf * scale, wf * scale), dtype=torch.float32, device=rows.device)
+    big = torch.empty((T, hf * rep * scale, wf * rep * scale), dtype=torch.float32, device=rows.device)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     with _dev_call(rows):
         _lib.check(lib.ocm_op_tile_postprocess(C.c_void_p(rows.data_ptr()), C.c_void_p(small.data_ptr()), T, H, nr, P, st))
-        _lib.check(lib.ocm_op_bilinear_upsample(C.c_void_p(small.data_ptr()), C.c_void_p(big.data_ptr()), T, hf, wf,
-                                                scale, st))
+        if rep > 1:  # pure index replication (the block values the //8 resize lands on)
+            small = small.repeat_interleave(rep, 1).repeat_interleave(rep, 2).contiguous()
+        _lib.check(lib.ocm_op_bilinear_upsample(C.c_void_p(small.data_ptr()), C.c_void_p(big.data_ptr()), T, hf * rep,
+                                                wf * rep, scale, st))
     return big
 
 
@@ -99,6 +105,64 @@ def stitch_windows(crops, stride, window):
         _lib.check(_lib.load().ocm_op_stitch(C.c_void_p(crops.data_ptr()), C.c_void_p(out.data_ptr()),
                                              C.c_void_p(ramp.data_ptr()), n, window, stride,
                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out
+
+
+def stitched_gray_image(slab, stride, window):
+    """sw_processing.py:224-227 on device: concat_crops of the uint8 RGB windows (float64 blends truncated into the
+    uint8 overlap at every fold) -> .convert("L"). slab: (C,H,W) float32 HIP tensor in [0,1] (the ToTensor image, C in
+    {1,3}). Returns ((S,S) uint8 image, 256-bin int64 histogram), S = window + (n-1)*stride. Bit-exact against the
+    reference's own functions (tests/golden/helpers.npz)."""
+    if not (slab.is_cuda and slab.dtype == torch.float32 and slab.dim() == 3 and slab.shape[0] in (1, 3)):
+        raise RuntimeError("stitched_gray_image needs a float32 (C,H,W) tensor, C in (1,3), on a HIP device")
+    if slab.stride(2) != 1:
+        slab = slab.contiguous()
+    n = window_count(slab.shape[1], stride)
+    if n <= 0 or n != window_count(slab.shape[2], stride):
+        raise ValueError("concat_crops stitches square window grids")
+    S = window + (n - 1) * stride
+    ramp = torch.from_numpy(np.linspace(1, 0, window - stride)).to(slab.device)
+    out = torch.empty((S, S), dtype=torch.uint8, device=slab.device)
+    hist = torch.empty(256, dtype=torch.int64, device=slab.device)
+    with _dev_call(slab):
+        _lib.check(_lib.load().ocm_op_stitch_image_u8(
+            C.c_void_p(slab.data_ptr()), int(slab.stride(0)), int(slab.stride(1)), int(slab.shape[0]), int(slab.shape[1]),
+            int(slab.shape[2]), C.c_void_p(out.data_ptr()), C.c_void_p(ramp.data_ptr()), n, window, stride,
+            C.c_void_p(hist.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    return out, hist
+
+
+def threshold(img_u8, heat, hist_img=None, as_numpy=False):
+    """threshold() of sw_processing.py:37-81 (save=False) on device: img_u8 (S,S) uint8 "L" image, heat (S,S) float32
+    stitched attention. Returns dict(th, th2, th3, result, attention, levels):
+      result = (img * attention / max(attention)).astype(uint8), attention = min_max_normalize(heat)     :42-46
+      th  = cv2 Otsu mask of result (:53), th2 = img > skimage Otsu level of img (:55-58), th3 = cv2 Otsu mask of
+      attention * 255 (:60). The Otsu levels are 256-step scalar loops over device histograms, evaluated on the host."""
+    from .utils import _otsu_from_hist, skimage_otsu_from_hist
+    if not (heat.is_cuda and heat.dtype == torch.float32 and img_u8.is_cuda and img_u8.dtype == torch.uint8):
+        raise RuntimeError("threshold needs a uint8 image and a float32 heat map on a HIP device (no CPU fallback)")
+    if tuple(img_u8.shape) != tuple(heat.shape):
+        raise ValueError(f"image {tuple(img_u8.shape)} and heat map {tuple(heat.shape)} differ in size")
+    heat, img_u8 = heat.contiguous(), img_u8.contiguous()
+    lib, dev, n = _lib.load(), heat.device, heat.numel()
+    if hist_img is None:
+        hist_img = torch.bincount(img_u8.reshape(-1).to(torch.int64), minlength=256)
+    res = torch.empty(heat.shape, dtype=torch.uint8, device=dev)
+    att = torch.empty(heat.shape, dtype=torch.uint8, device=dev)
+    masks = torch.empty((3,) + tuple(heat.shape), dtype=torch.uint8, device=dev)
+    scratch = torch.empty(2048, dtype=torch.uint8, device=dev)
+    h_res = torch.empty(256, dtype=torch.int64, device=dev)
+    h_att = torch.empty(256, dtype=torch.int64, device=dev)
+    vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    with _dev_call(heat):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.ocm_op_weighted_u8(vp(heat), vp(img_u8), n, vp(scratch), vp(res), vp(att), vp(h_res), vp(h_att), st))
+        levels = (_otsu_from_hist(h_res, n), skimage_otsu_from_hist(hist_img), _otsu_from_hist(h_att, n))
+        for k, src in enumerate((res, img_u8, att)):
+            _lib.check(lib.ocm_op_threshold_u8(vp(src), vp(masks[k]), n, levels[k], st))
+    out = dict(th=masks[0], th2=masks[1], th3=masks[2], result=res, attention=att, levels=levels)
+    if as_numpy:
+        out = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}
     return out
 
 
@@ -186,8 +250,13 @@ class SlidingWindowAttention:
     @torch.no_grad()
     def segment(self, slab):
         """The whole of sw_processing.py:223-262 on device: windows -> CLS-row maps (sharded, all-gathered)
-        -> per-window head mean / min-max / x p bilinear upsample -> overlap-blended stitch -> Otsu mask of
-        the heat map. Returns dict(maps, heat (S,S) fp32, image (S,S) uint8, mask (S,S) uint8, level)."""
+        -> per-window head mean / min-max / down-up resize -> overlap-blended stitch of the maps AND of the uint8
+        image -> threshold(): the three masks the reference returns. Returns dict(
+          maps, heat (S,S) fp32 stitched attention, gray (S,S) uint8 stitched "L" image,
+          th (Otsu of image x attention), th2 (skimage Otsu of the image), th3 = mask (Otsu of the heat map),
+          result, image (= attention * 255 as uint8), level (of th3), levels (all three))."""
+        if slab.dim() == 4:
+            slab = slab[0]
         maps = self(slab)
         T, Hh, _, hf, wf = maps.shape
         n = int(round(T ** 0.5))
@@ -195,5 +264,7 @@ class SlidingWindowAttention:
             raise ValueError("segment() stitches square window grids (as concat_crops does)")
         up = postprocess_windows(maps.reshape(T, Hh, 1, hf * wf), hf, wf, self.window // hf)
         heat = stitch_windows(up, self.stride, self.window)
-        image, mask, level = otsu_heatmap_mask(heat)
-        return dict(maps=maps, heat=heat, image=image, mask=mask, level=level)
+        gray, hist_gray = stitched_gray_image(slab, self.stride, self.window)
+        t = threshold(gray, heat, hist_img=hist_gray)
+        return dict(maps=maps, heat=heat, gray=gray, th=t["th"], th2=t["th2"], th3=t["th3"], mask=t["th3"],
+                    result=t["result"], image=t["attention"], level=t["levels"][2], levels=t["levels"])

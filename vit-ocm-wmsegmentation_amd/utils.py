@@ -57,6 +57,27 @@ def _otsu_from_hist(hist_dev, count):
     return level
 
 
+def skimage_otsu_from_hist(hist_dev):
+    """skimage.filters.threshold_otsu (0.19.3, sw_processing.py:57) from a 256-bin device histogram of a uint8 image:
+    integer bins over [min, max], float64 class weights / means, first maximum of the between-class variance
+    (a 256-step scalar computation: on the host, like the reference). scikit-image is not installable here:
+    restated from its source, parity unpinned."""
+    h = hist_dev.cpu().numpy().astype(np.float64)
+    nz = np.nonzero(h)[0]
+    if nz.size == 0:
+        raise ValueError("empty histogram")
+    lo, hi = int(nz[0]), int(nz[-1])
+    if lo == hi:
+        return lo
+    counts, centers = h[lo:hi + 1], np.arange(lo, hi + 1)
+    weight1 = np.cumsum(counts)
+    weight2 = np.cumsum(counts[::-1])[::-1]
+    mean1 = np.cumsum(counts * centers) / weight1
+    mean2 = (np.cumsum((counts * centers)[::-1]) / weight2[::-1])[::-1]
+    variance12 = weight1[:-1] * weight2[1:] * (mean1[:-1] - mean2[1:]) ** 2
+    return int(centers[int(np.argmax(variance12))])
+
+
 def image_to_gray_u8(img):
     """transform(img.squeeze(0)).convert("L") of eval.py:166 on device: (C,H,W) or (1,C,H,W) float tensor in
     [0,1] with C in {1,3} -> ((H,W) uint8 tensor, 256-bin int64 histogram)."""
