@@ -223,7 +223,8 @@ def test_stitched_gray_image_bit_exact_vs_reference_fixture(dev):
         gray, hist = sw.stitched_gray_image(s, 32, 96)
         assert np.array_equal(gray.cpu().numpy(), gold["stitch_u8_gray"])
         assert np.array_equal(hist.cpu().numpy(), np.bincount(gold["stitch_u8_gray"].ravel(), minlength=256))
-    assert (gold["stitch_u8_gray"] != img).any()  # the truncating blend really changes pixels: not a plain copy
+    # (for windows cut from ONE image the truncating blend v*w + v*(1-w) lands back on v: the stitched image equals the
+    # source here; the fold / truncation itself is pinned on independent windows in test_oracle_golden.py)
     # a slab whose windows reach past the edge (PIL crop zero fill) against the oracle
     img2 = rng.integers(0, 256, (200, 200), dtype=np.uint8)
     g2, _ = sw.stitched_gray_image(torch.from_numpy(img2.astype(np.float32) / 255.0)[None].to(dev), 32, 96)
@@ -268,7 +269,7 @@ def test_segment_returns_reference_masks(dev):
         assert np.array_equal(out[k].cpu().numpy(), want), k
 
 
-@pytest.mark.parametrize("median", [3, 9])
+@pytest.mark.parametrize("median", [3, 13])
 def test_segment_images_median_filter_and_crops(dev, median):
     """eval.py --median_filter k and --crop 4: one batched forward for all crops, then the reference's per-crop median,
     utils.concat_crops tiling and resize chain (oracle, crop by crop at B = 1 like the reference's loop)."""
@@ -295,6 +296,7 @@ def test_segment_images_median_filter_and_crops(dev, median):
     for b in range(B):
         want = O.threshold_masks(O.to_pil_gray_u8(gray[b].numpy()), maps[b])[0][0]
         assert np.mean(masks[b] != want) == 0.0  # same map in, same mask out
-    # median 9 > p - 1 really changes the map; median 3 <= p - 1 is the identity on what survives the down-scale
+    # a 13 x 13 window holds more foreign than own-block pixels and really changes the map; a 3 x 3 window around the
+    # block-centre pixels the down-scale samples lies inside one constant block: the identity
     base = average_attention_maps(model, crops.to(dev), median_filter=1).cpu().numpy()
-    assert (np.abs(maps - base).max() > 0) == (median > p - 1)
+    assert (np.abs(maps - base).max() > 0) == (median == 13)
