@@ -69,7 +69,8 @@ def host_cores():
 
 
 def cpu_baseline(arch_dims, patch, size, batch, seconds_budget=20.0):
-    """The oracle (CPU restatement of the reference, fp32 torch-CPU ops) timed on this host."""
+    """The oracle (CPU restatement of the reference, fp32 torch-CPU ops) timed on this host: at the bench batch and at
+    B = 1, which is how the reference's own loops call the model (eval.py:128-136, sw_processing.py:235-239)."""
     from oracle import vit_oracle as O  # CPU baseline leg: allowed importer of oracle/
     from vit_ocm_wmsegmentation_amd import synth
     D, L, H = arch_dims
@@ -85,9 +86,81 @@ def cpu_baseline(arch_dims, patch, size, batch, seconds_budget=20.0):
         O.get_last_selfattention(sd, cfg, x)
         iters += 1
     dt = time.perf_counter() - t0
+    x1 = x[:1]
+    O.get_last_selfattention(sd, cfg, x1)
+    t1 = time.perf_counter()
+    it1 = 0
+    while it1 < 40 and time.perf_counter() - t1 < 4.0:
+        O.get_last_selfattention(sd, cfg, x1)
+        it1 += 1
+    dt1 = time.perf_counter() - t1
     return {"value": round(batch * iters / dt, 2), "unit": "tiles/s", "cores": cores, "kind": "port",
+            "b1_value": round(it1 / dt1, 2),
             "sample": f"{iters} batches of {batch} tiles ({size}x{size}, get_last_selfattention, fp32 torch-CPU "
-                      f"oracle, {cores} threads) after 1 warm-up"}
+                      f"oracle, {cores} threads) after 1 warm-up; b1_value = {it1} single-tile calls (the reference's "
+                      f"callers run B = 1)"}
+
+
+def slab_sweep(args, dev, world, rank, lib):
+    """BASELINE.json configs[3] — the path north_star prices at 8 GPUs: ViT-S/8 sliding-window sweep of a 4096^2 slab
+    (900 windows of 384^2, N = 2305) sharded over the ranks with one all-gather of the CLS-row maps. STRONG scaling:
+    the slab is fixed, every rank runs its block of windows. All ranks call this; rank 0 returns the report."""
+    import ctypes as C
+
+    import vit_ocm_wmsegmentation_amd.dino.vision_transformer as vits
+    from vit_ocm_wmsegmentation_amd import _lib, synth
+    from vit_ocm_wmsegmentation_amd.sw_processing import SlidingWindowAttention
+    model = vits.vit_small(patch_size=8, num_classes=0)
+    model.load_state_dict(synth.synth_arch_state_dict("vit_small", 8, seed=0, variant="init"))
+    model.eval().to(dev).set_precision(args.precision)
+    slab = synth.synth_tiles(1, args.slab_size, seed=7)[0].to(dev)
+    sweep = SlidingWindowAttention(model, window=384, stride=128, batch_tiles=16)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+    maps = sweep(slab)  # warm-up (engine build, workspace, RCCL channel)
+    sync()
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        maps = sweep(slab)
+    sync()
+    dt = (time.perf_counter() - t0) / reps
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    # dominant kernel of this rank's share, timed with HIP events on the launch stream (rank 0)
+    roof = None
+    if rank == 0:
+        ms = (C.c_double * len(_lib.KERNEL_CLASSES))()
+        cnt = (C.c_int64 * len(_lib.KERNEL_CLASSES))()
+        _lib.check(lib.ocm_prof_begin(0xFFFFFFFF, 4096))
+        sweep(slab)
+        torch.cuda.synchronize()
+        _lib.check(lib.ocm_prof_end(ms, cnt))
+        D, Hh, N, B = 384, 6, 2305, 16
+        cf = class_flops(D, 4 * D, N, B, 8, 3)
+        dom = max((c for c in _lib.KERNEL_CLASSES if c in cf), key=lambda c: ms[_lib.KERNEL_CLASSES.index(c)])
+        i = _lib.KERNEL_CLASSES.index(dom)
+        avg_s = ms[i] / max(cnt[i], 1) * 1e-3
+        mpp = 3 if args.precision == "bf16x3" else 1
+        peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_DENSE_TFLOPS
+        ach = cf[dom] / avg_s / 1e12
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": None, "launches": int(cnt[i]), "avg_launch_us": round(avg_s * 1e6, 2),
+                "flop_per_launch": cf[dom], "mfma_per_product": mpp, "mfma_pipe_frac": round(ach * mpp / peak, 4),
+                "note": "per launch of 16 windows (the last launches of a rank hold 14-15)"}
+    T = maps.shape[0]
+    fwin, _ = flops_per_tile(384, 12, 8, 384)
+    if rank != 0:
+        return None
+    return {"workload": f"vit_small patch 8, {args.slab_size}^2 slab -> {T} windows of 384^2 (N=2305), 16 windows per forward, "
+                        f"CLS-row maps, tile shard x{world} + one all-gather", "scaling": "strong", "n_gpus": world,
+            "windows": T, "ms_per_sweep": round(dt * 1e3, 2), "value": round(T / dt, 1), "unit": "windows/s",
+            "path_tflops": round(T / dt * fwin / 1e12, 2), "roofline": roof}
 
 
 def main():
@@ -103,6 +176,8 @@ def main():
                     help="operand precision of the contraction kernels. Default: bf16x3 (split-bf16 on the bf16 MFMA), the "
                          "fastest mode that holds the north star's 1e-3 on every golden weight set")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-slab", action="store_true", help="skip the sharded 4096^2 slab sweep (BASELINE configs[3]) extra")
+    ap.add_argument("--slab-size", type=int, default=4096)
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-class table to stderr")
     args = ap.parse_args()
 
@@ -218,26 +293,44 @@ def main():
             for k, v in breakdown.items():
                 print(f"  {k:12s} {v}", file=sys.stderr)
 
+    # the sharded slab sweep (strong scaling; all ranks take part), outside the timed region of the headline metric
+    default_workload = (args.arch, p, S) == ("vit_small", 16, 224)
+    slab = None
+    if default_workload and not args.no_slab:
+        del out
+        slab = slab_sweep(args, dev, world, rank, lib)
+        out = model._run(x, flags=flags)
+
     if rank != 0:
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    # parity of what was just timed: attention-map L_inf vs the CPU oracle on the first tiles
+    # parity of what was just timed: attention-map L_inf vs the CPU oracle on the first tiles of the bench batch, for the
+    # random-init weights of the timed run and for the sharp (qkv x4) and peaked (qkv x8, attention max ~0.8: what a
+    # trained checkpoint looks like) weight sets pushed through the same engine at the same batch
     from oracle import vit_oracle as O  # checker
-    sd = synth.synth_arch_state_dict(args.arch, p, seed=0, variant="init")
-    cfg = O.make_cfg(sd, p, H)
     nchk = min(2, B)
-    ref = O.get_last_selfattention(sd, cfg, x[:nchk].cpu())
-    linf = float((out["attn"][0][:nchk].cpu() - ref).abs().max())
+    linf_by_set = {}
+    for variant in ("init", "sharp", "peaked"):
+        sd = synth.synth_arch_state_dict(args.arch, p, seed=0, variant=variant)
+        cfg = O.make_cfg(sd, p, H)
+        ref = O.get_last_selfattention(sd, cfg, x[:nchk].cpu())
+        if variant == "init":
+            got = out["attn"][0][:nchk]
+        else:
+            model.load_state_dict(sd)
+            got = model._run(x, flags=flags)["attn"][0][:nchk]
+        linf_by_set[variant] = {"linf": float((got.cpu() - ref).abs().max()), "attn_max": round(float(ref.max()), 4)}
+    linf = linf_by_set["init"]["linf"]
 
     # HBM bytes per launch of the dominant class: measured offline with rocprofv3 --pmc (separate passes,
     # gfx950 FETCH_SIZE correction) and committed under profiles/; only valid for the default workload
     traffic = None
-    if (args.arch, p, S, B, args.precision) == ("vit_small", 16, 224, 64, "bf16"):
+    if (args.arch, p, S, B) == ("vit_small", 16, 224, 64):
         try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[dom]["traffic_bytes"]
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[args.precision][dom]["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             traffic = None
     tiles = B * world * args.steps
@@ -265,6 +358,7 @@ def main():
                                f"get_last_selfattention -> (B,{H},{N},{N}) fp32 + CLS-row maps; random-init weights",
                    "tiles_per_gpu": B, "tokens": N, "parallelism": f"tile-shard x{world}" + (" + all-gather" if world > 1 else "")},
         "attn_linf_vs_cpu_oracle": linf,
+        "attn_linf_by_weight_set": linf_by_set,
         "path_tflops": round(value * fmap / 1e12, 2),
         "path_frac_of_mfma_peak": round(value * fmap / 1e12 / (peak * world), 4),
         "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2) if achieved else None,
@@ -275,6 +369,8 @@ def main():
                      "mfma_pipe_frac": round(achieved * mfma_per_product / peak, 4) if achieved else None},
         "kernel_breakdown": breakdown,
     }
+    if slab is not None:
+        line["slab_sweep"] = slab
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline((D, L, H), p, S, B)
     print(json.dumps(line))

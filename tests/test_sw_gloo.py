@@ -65,6 +65,78 @@ def test_sharded_sweep_equals_serial(tmp_path, world, size):
         assert got.shape == ref.shape and np.array_equal(got, ref), f"rank {r}"
 
 
+class _CpuSweep(sw.SlidingWindowAttention):
+    """SlidingWindowAttention with its two device-touching steps replaced by CPU stand-ins: everything else —
+    origins, zero padding, sharding, the balanced batch plan, the padded local buffer, the all-gather, the final
+    order — is the product's own __call__."""
+    P, HEADS = 8, 2
+
+    def __init__(self, **kw):
+        super().__init__(model=None, **kw)
+        self.batches = []
+
+    def _geometry(self, device):
+        return self.P, self.HEADS, None
+
+    def _forward_batch(self, slab, origins_dev, nb, pos, query_rows):
+        assert origins_dev.shape == (nb, 2) and origins_dev.dtype == torch.int32
+        self.batches.append(nb)
+        hf = self.window // self.P
+        out = torch.empty((nb, self.HEADS, 1, hf * hf))
+        for i in range(nb):
+            y0, x0 = int(origins_dev[i, 0]), int(origins_dev[i, 1])
+            t = slab[:, y0:y0 + self.window, x0:x0 + self.window]
+            assert t.shape[1:] == (self.window, self.window)  # the (padded) slab covers every window
+            pooled = torch.nn.functional.avg_pool2d(t[None], self.P)[0]  # (C, hf, hf): a per-patch "map"
+            out[i, 0, 0] = pooled[0].reshape(-1)
+            out[i, 1, 0] = pooled[0].reshape(-1) * 0.5 + float(y0 * 1000 + x0)
+        return out
+
+
+def _call_worker(rank, world, port, size, window, stride, batch_tiles, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(7)
+        slab = torch.rand(3, size, size, generator=g)
+        sweep = _CpuSweep(window=window, stride=stride, batch_tiles=batch_tiles)
+        maps = sweep(slab)
+        np.save(os.path.join(out_dir, f"call_{rank}.npy"), maps.numpy())
+        np.save(os.path.join(out_dir, f"batches_{rank}.npy"), np.array(sweep.batches))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size,window,stride,batch_tiles", [(2, 160, 96, 32, 2), (3, 200, 96, 32, 4), (2, 130, 96, 32, 16)])
+def test_call_itself_sharded_over_gloo_equals_single_process(tmp_path, world, size, window, stride, batch_tiles):
+    """SlidingWindowAttention.__call__ (not a re-implementation of its loop) with world 2 / 3 over gloo: every rank ends
+    with all windows in row-major order, identical to the single-process call; per-rank batches are balanced; slabs
+    whose windows reach past the edge (200, 130) are zero-padded."""
+    port = _free_port()
+    mp.spawn(_call_worker, args=(world, port, size, window, stride, batch_tiles, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(7)
+    single = _CpuSweep(window=window, stride=stride, batch_tiles=batch_tiles)
+    ref = single(torch.rand(3, size, size, generator=g)).numpy()
+    n = len(range(0, size - 2 * stride, stride))
+    assert ref.shape == (n * n, 2, 1, window // 8, window // 8)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"call_{r}.npy"), ref), f"rank {r}"
+        b = np.load(tmp_path / f"batches_{r}.npy")
+        begin, end, _ = sw.shard_range(n * n, world, r)
+        assert b.sum() == end - begin and (b.size == 0 or (b.max() - b.min() <= 1 and b.max() <= batch_tiles))
+
+
+def test_batch_plan_is_balanced():
+    plan = sw.SlidingWindowAttention.batch_plan
+    assert plan(113, 16) == [15, 14, 14, 14, 14, 14, 14, 14]  # a rank's share of 900 windows on 8 GPUs: no B = 1 tail
+    assert plan(109, 16) == [16, 16, 16, 16, 15, 15, 15]
+    for count, bt in ((900, 16), (113, 16), (109, 16), (5, 8), (16, 16), (17, 16), (1, 4), (0, 4)):
+        p = plan(count, bt)
+        assert sum(p) == count and all(0 < x <= bt for x in p) and (not p or max(p) - min(p) <= 1)
+        assert len(p) == -(-count // bt)
+
+
 def test_gather_is_identity_without_process_group():
     local = torch.arange(12.).reshape(4, 3)
     assert torch.equal(sw.gather_tile_maps(local, 3), local[:3])

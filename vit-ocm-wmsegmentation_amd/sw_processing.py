@@ -201,6 +201,32 @@ class SlidingWindowAttention:
     def __init__(self, model, window=384, stride=128, batch_tiles=16, group=None):
         self.model, self.window, self.stride, self.batch_tiles, self.group = model, window, stride, batch_tiles, group
 
+    # ---- the two device-touching steps, overridable (tests/test_sw_gloo.py drives __call__ on CPU through them) ----
+    def _geometry(self, device):
+        """(patch size, heads) of the model and the (N, D) positional table of one window on `device`."""
+        m = self.model
+        eng = m._engine(device)
+        hf = self.window // eng.p
+        return eng.p, eng.H, m._pos_for(hf * hf, self.window, self.window, device)
+
+    def _forward_batch(self, slab, origins_dev, nb, pos, query_rows):
+        """CLS-row (or `query_rows`) maps of `nb` windows of the resident slab: (nb, heads, n_rows, hf*wf) fp32. The
+        windows are gathered in place through their origins (no crops are materialised)."""
+        eng = self.model._engine(slab.device)
+        out = eng.forward_tiles(slab, (0, slab.stride(0), slab.stride(1)), origins_dev, nb, self.window, self.window, pos,
+                                flags=_lib.OCM_OUT_ROWS | _lib.OCM_LAST_ATTN_ONLY, query_rows=query_rows)
+        return out["rows"]
+
+    @staticmethod
+    def batch_plan(count, batch_tiles):
+        """Split `count` windows into ceil(count / batch_tiles) batches whose sizes differ by at most one (113 windows
+        at 16 per forward -> 15 + 7 x 14 rather than 7 x 16 + a lone B = 1 forward that costs 4x its share)."""
+        if count <= 0:
+            return []
+        nb = -(-count // max(1, batch_tiles))
+        base, extra = divmod(count, nb)
+        return [base + (1 if i < extra else 0) for i in range(nb)]
+
     @torch.no_grad()
     def __call__(self, slab, query_rows=None):
         """slab: (C, H, W) or (1, C, H, W) fp32 HIP tensor. Returns (T, heads, n_rows, hf, wf) fp32
@@ -210,9 +236,8 @@ class SlidingWindowAttention:
         if slab.stride(2) != 1:
             slab = slab.contiguous()
         m, dev = self.model, slab.device
-        eng = m._engine(dev)
-        p, Hh = eng.p, eng.H
-        if m._gray_fold and slab.shape[0] == 3:
+        p, Hh, pos = self._geometry(dev)
+        if getattr(m, "_gray_fold", False) and slab.shape[0] == 3:
             slab = slab[:1]
         origins = sliding_window_origins(slab.shape[1], slab.shape[2], self.stride)
         T = origins.shape[0]
@@ -236,14 +261,11 @@ class SlidingWindowAttention:
         hf = wf = self.window // p
         nq = 1 if query_rows is None else int(query_rows.numel())
         local = torch.zeros((share, Hh, nq, hf * wf), dtype=torch.float32, device=dev)
-        pos = m._pos_for(hf * wf, self.window, self.window, dev)
         dev_origins = torch.from_numpy(origins[begin:end]).to(dev)
-        strides = (0, slab.stride(0), slab.stride(1))
-        for s in range(0, end - begin, self.batch_tiles):
-            nb = min(self.batch_tiles, end - begin - s)
-            out = eng.forward_tiles(slab, strides, dev_origins[s:s + nb].contiguous(), nb, self.window, self.window, pos,
-                                    flags=_lib.OCM_OUT_ROWS | _lib.OCM_LAST_ATTN_ONLY, query_rows=query_rows)
-            local[s:s + nb] = out["rows"]
+        s = 0
+        for nb in self.batch_plan(end - begin, self.batch_tiles):
+            local[s:s + nb] = self._forward_batch(slab, dev_origins[s:s + nb].contiguous(), nb, pos, query_rows)
+            s += nb
         maps = gather_tile_maps(local, T, self.group)
         return maps.reshape(T, Hh, nq, hf, wf)
 
