@@ -132,15 +132,16 @@ def slab_sweep(args, dev, world, rank, lib):
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    # dominant kernel of this rank's share, timed with HIP events on the launch stream (rank 0)
+    # dominant kernel of a rank's share, timed with HIP events on the launch stream. The sweep ends in a collective, so
+    # EVERY rank runs this extra pass (each profiles its own launches); rank 0 reports its figures.
     roof = None
+    ms = (C.c_double * len(_lib.KERNEL_CLASSES))()
+    cnt = (C.c_int64 * len(_lib.KERNEL_CLASSES))()
+    _lib.check(lib.ocm_prof_begin(0xFFFFFFFF, 4096))
+    sweep(slab)
+    torch.cuda.synchronize()
+    _lib.check(lib.ocm_prof_end(ms, cnt))
     if rank == 0:
-        ms = (C.c_double * len(_lib.KERNEL_CLASSES))()
-        cnt = (C.c_int64 * len(_lib.KERNEL_CLASSES))()
-        _lib.check(lib.ocm_prof_begin(0xFFFFFFFF, 4096))
-        sweep(slab)
-        torch.cuda.synchronize()
-        _lib.check(lib.ocm_prof_end(ms, cnt))
         D, Hh, N, B = 384, 6, 2305, 16
         cf = class_flops(D, 4 * D, N, B, 8, 3)
         dom = max((c for c in _lib.KERNEL_CLASSES if c in cf), key=lambda c: ms[_lib.KERNEL_CLASSES.index(c)])
