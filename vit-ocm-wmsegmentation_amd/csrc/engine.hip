@@ -331,15 +331,21 @@ static int check_ws(const ocm_vit *h, int batch, int n, void *ws, size_t ws_byte
 }
 
 // Block.forward (:106-114). x is updated in place unless attn_only.
+// `xn_ready`: w.xn already holds norm1(x) (written by the previous block's fused fc2 epilogue). `next_g` / `next_b`: the
+// LayerNorm that consumes this block's output next (the next block's norm1) — when given and the embedding width has a
+// fused kernel, fc2's epilogue writes it into w.xn and *xn_out is set.
 static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int batch, int n, bool attn_only,
                      float *out_attn, float *out_qkv, const int32_t *query_rows, int n_rows, float *out_rows,
-                     hipStream_t s) {
+                     hipStream_t s, bool xn_ready = false, const float *next_g = nullptr, const float *next_b = nullptr,
+                     bool *xn_out = nullptr) {
     const BlockP &bp = h->blk[i];
     const int D = h->D, H = h->H, T = batch * n, np = ocm_n_pad_for(h->prec, n);
     const float eps = h->cfg.ln_eps, scale = h->cfg.qk_scale;
     const int pc = h->prec, lnk = ln_kind_of_prec(pc);
+    const bool fuse_ln = linear_resid_ln_supported(D) && g_ocm_knobs[5] != 1;  // knob 5 = 1: separate LayerNorm launches
+    if (xn_out) *xn_out = false;
     // y = attn(norm1(x))
-    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, lnk, T, D, eps, s)); }
+    if (!xn_ready) { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, lnk, T, D, eps, s)); }
     // a block that stops after its probabilities (get_last_selfattention) and returns no qkv never reads V
     const bool want_v = !(attn_only && !out_qkv);
     if (h->hd != 64) {  // generic heads: fp32 qkv tensor -> fp32 FMA attention
@@ -367,12 +373,24 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
         if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
     }
     }
-    // x = x + proj(ctx)
-    { PROF(OCM_K_PROJ, s); HIP_TRY(launch_linear(pc, w.ctx, h->ptr<char>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s)); }
-    // x = x + fc2(gelu(fc1(norm2(x))))
-    { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln2_g), h->ptr<float>(bp.ln2_b), w.xn, lnk, T, D, eps, s)); }
+    // x = x + proj(ctx); xn = norm2(x) — one kernel when the workgroup can own full rows
+    if (fuse_ln) {
+        PROF(OCM_K_PROJ, s);
+        HIP_TRY(launch_linear_resid_ln(pc, w.ctx, h->ptr<char>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, h->ptr<float>(bp.ln2_g), h->ptr<float>(bp.ln2_b), w.xn, T, D, D, eps, s));
+    } else {
+        { PROF(OCM_K_PROJ, s); HIP_TRY(launch_linear(pc, w.ctx, h->ptr<char>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s)); }
+        { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln2_g), h->ptr<float>(bp.ln2_b), w.xn, lnk, T, D, eps, s)); }
+    }
+    // x = x + fc2(gelu(fc1(xn))) [; xn = the next block's norm1(x)]
     { PROF(OCM_K_FC1, s); HIP_TRY(launch_linear(pc, w.xn, h->ptr<char>(bp.fc1_w), h->ptr<float>(bp.fc1_b), nullptr, w.hid, T, h->M, D, OCM_EPI_BIAS_GELU_BF16, s)); }
-    { PROF(OCM_K_FC2, s); HIP_TRY(launch_linear(pc, w.hid, h->ptr<char>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s)); }
+    if (fuse_ln && next_g && next_b) {
+        PROF(OCM_K_FC2, s);
+        HIP_TRY(launch_linear_resid_ln(pc, w.hid, h->ptr<char>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, next_g, next_b, w.xn, T, D, h->M, eps, s));
+        if (xn_out) *xn_out = true;
+    } else {
+        PROF(OCM_K_FC2, s);
+        HIP_TRY(launch_linear(pc, w.hid, h->ptr<char>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s));
+    }
     return OCM_OK;
 }
 
@@ -446,13 +464,16 @@ static int enqueue_forward(ocm_vit *h, const ocm_vit_io *io, int n, hipStream_t 
     const Workspace w = carve(h, B, n, (char *)io->workspace);
     if ((rc = run_prepare(h, io, w.x, n, s))) return rc;
     const size_t T = (size_t)B * n;
+    bool xn_ready = false;  // w.xn holds the next block's norm1(x) (fused into the previous fc2)
     for (int i = 0; i < L; ++i) {
         const int slot = i - (L - io->n_last);  // >= 0 for the returned blocks
         const bool ret = slot >= 0, last = i == L - 1;
         float *oa = (ret && (fl & OCM_OUT_ATTN)) ? io->out_attn + (size_t)slot * B * h->H * n * n : nullptr;
         float *oq = (ret && (fl & OCM_OUT_QKV)) ? io->out_qkv + (size_t)slot * 3 * B * h->H * n * h->hd : nullptr;
         float *orow = (last && (fl & OCM_OUT_ROWS)) ? io->out_rows : nullptr;
-        if ((rc = run_block(h, i, w, w.x, B, n, attn_only && last, oa, oq, io->query_rows, io->n_rows, orow, s)))
+        const float *ng = last ? nullptr : h->ptr<float>(h->blk[i + 1].ln1_g), *nb = last ? nullptr : h->ptr<float>(h->blk[i + 1].ln1_b);
+        if ((rc = run_block(h, i, w, w.x, B, n, attn_only && last, oa, oq, io->query_rows, io->n_rows, orow, s, xn_ready, ng, nb,
+                            &xn_ready)))
             return rc;
         if (ret && (fl & OCM_OUT_FEAT)) {
             PROF(OCM_K_LN, s);

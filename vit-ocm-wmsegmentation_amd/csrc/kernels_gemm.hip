@@ -276,6 +276,136 @@ hipError_t launch_linear(int prec, const void *a, const void *w, const float *bi
 }
 
 // ------------------------------------------------------------------------------------------
+// proj / fc2 + residual + the LayerNorm that follows (Block.forward :110-111 then :107 / :111 of the next use)
+// ------------------------------------------------------------------------------------------
+// A workgroup owns FULL rows (tile 64 x D), so after x = resid + acc its epilogue can normalise the rows it has just
+// produced and hand the next GEMM its operand directly: one launch and one read + write of the residual stream less
+// per LayerNorm (23 -> 1 LayerNorm launches per ViT-S forward). Statistics are the two-pass fp32 form of
+// layernorm_v4_kernel (half a wavefront per row, the row in registers), on exactly the fp32 values written to x.
+template <class OE, int D_>
+struct EpiResidLN {
+    const float *bias;
+    const float *resid;
+    float *x;           // [M][D] fp32 residual stream out (may alias resid)
+    const float *gamma, *beta;
+    void *xn;           // [M][D] OE: LayerNorm(x) for the next GEMM
+    int M;
+    float eps;
+    template <class Cfg>
+    __device__ __forceinline__ void run(const float *C, int m0, int) const {
+        constexpr int BM = Cfg::BM, NT = Cfg::NT, NV = D_ / 128;
+        static_assert(Cfg::BN == D_ && D_ % 128 == 0, "full rows, float4 lanes");
+        const int sub = threadIdx.x & 31, half = threadIdx.x >> 5;  // half-wavefront per row
+        constexpr int RPP = NT / 32;                                   // rows per pass
+        f32x4 g[NV], b[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            g[i] = *(const f32x4 *)(gamma + sub * 4 + i * 128);
+            b[i] = *(const f32x4 *)(beta + sub * 4 + i * 128);
+        }
+#pragma unroll 2
+        for (int r0 = 0; r0 < BM; r0 += RPP) {
+            const int row = r0 + half, m = m0 + row;
+            if (m >= M) continue;  // no barriers below
+            f32x4 v[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i] = *(const f32x4 *)(resid + (int64_t)m * D_ + sub * 4 + i * 128);
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                v[i] += *(const f32x4 *)(C + row * D_ + sub * 4 + i * 128);
+                *(f32x4 *)(x + (int64_t)m * D_ + sub * 4 + i * 128) = v[i];
+                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            const float mean = s * (1.0f / D_);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[i][e] - mean;
+                    q = fmaf(d, d, q);
+                }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+            const float rstd = 1.0f / sqrtf(q * (1.0f / D_) + eps);
+            char *rowp = (char *)xn + (int64_t)m * D_ * (int)sizeof(OE);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = sub * 4 + i * 128;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[i][e] + b[i][e];
+                if constexpr (Elem<OE>::MODE == 0) {
+                    bf16x4 ob;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ob[e] = (bf16)o[e];
+                    *(bf16x4 *)(rowp + c * 2) = ob;
+                } else if constexpr (Elem<OE>::MODE == 1) {
+                    *(f32x4 *)(rowp + c * 4) = o;
+                } else {
+                    bf16x4 hi, lo;
+                    split4(o, hi, lo);
+                    *(bf16x4 *)(rowp + sp_off(c)) = hi;
+                    *(bf16x4 *)(rowp + sp_off(c) + 64) = lo;
+                }
+            }
+        }
+    }
+};
+
+template <class E, int D_>
+static hipError_t launch_resid_ln_d(const E *a, const E *w, const float *bias, const float *resid, float *x,
+                                    const float *gamma, const float *beta, void *xn, int M, int K, float eps,
+                                    hipStream_t s) {
+    typedef GemmCfg<64, D_, 2, 4> Cfg;  // 8 waves, wave tile 32 x D/4
+    EpiResidLN<E, D_> epi{bias, resid, x, gamma, beta, xn, M, eps};
+    if constexpr (Elem<E>::MODE == 2) {
+        // One 8-wave workgroup per CU: the two-step register prefetch hides more latency than a two-stage LDS-DMA ring
+        // (fc2 + LayerNorm at ViT-S/16, B = 64: 72 us against 89 us), and a third stage does not fit next to the
+        // 96 KiB epilogue image. Knob 4 = 2 forces the DMA loop (development A/B).
+        if (g_ocm_knobs[4] == 2) {
+            if (K % Elem<E>::KROW) return hipErrorInvalidValue;
+            switch (K / Elem<E>::KROW) {
+                case 12: return launch_gemm_dma_ks<Cfg, E, 12, 2>(a, K, w, K, M, D_, K, epi, s);
+                case 48: return launch_gemm_dma_ks<Cfg, E, 48, 2>(a, K, w, K, M, D_, K, epi, s);
+                default: return launch_gemm_dma_ks<Cfg, E, 0, 2>(a, K, w, K, M, D_, K, epi, s);
+            }
+        }
+    }
+    RowLoader<E> al{a, K};
+    return launch_gemm<Cfg, E, false>(al, w, K, M, D_, K, epi, s);
+}
+
+template <class E>
+static hipError_t launch_resid_ln_e(const E *a, const E *w, const float *bias, const float *resid, float *x,
+                                    const float *gamma, const float *beta, void *xn, int M, int D, int K, float eps,
+                                    hipStream_t s) {
+    switch (D) {
+        case 128: return launch_resid_ln_d<E, 128>(a, w, bias, resid, x, gamma, beta, xn, M, K, eps, s);
+        case 256: return launch_resid_ln_d<E, 256>(a, w, bias, resid, x, gamma, beta, xn, M, K, eps, s);
+        case 384: return launch_resid_ln_d<E, 384>(a, w, bias, resid, x, gamma, beta, xn, M, K, eps, s);
+        case 512: return launch_resid_ln_d<E, 512>(a, w, bias, resid, x, gamma, beta, xn, M, K, eps, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+bool linear_resid_ln_supported(int D) { return D == 128 || D == 256 || D == 384 || D == 512; }
+
+// x = resid + A W^T + bias;  xn = LayerNorm(x; gamma, beta, eps) in the activation type of `prec`
+hipError_t launch_linear_resid_ln(int prec, const void *a, const void *w, const float *bias, const float *resid, float *x,
+                                  const float *gamma, const float *beta, void *xn, int M, int D, int K, float eps,
+                                  hipStream_t s) {
+    if (prec == 2)
+        return launch_resid_ln_e<sp32>((const sp32 *)a, (const sp32 *)w, bias, resid, x, gamma, beta, xn, M, D, K, eps, s);
+    if (prec)
+        return launch_resid_ln_e<float>((const float *)a, (const float *)w, bias, resid, x, gamma, beta, xn, M, D, K, eps, s);
+    return launch_resid_ln_e<bf16>((const bf16 *)a, (const bf16 *)w, bias, resid, x, gamma, beta, xn, M, D, K, eps, s);
+}
+
+// ------------------------------------------------------------------------------------------
 // qkv projection -> head-major q, k and key-contiguous V^T
 // ------------------------------------------------------------------------------------------
 // Wqkv rows are ordered q(h0..hH-1), k(...), v(...), each head's 64 rows contiguous (:80).
