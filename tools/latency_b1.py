@@ -13,10 +13,11 @@ import vit_ocm_wmsegmentation_amd.dino.vision_transformer as vits  # noqa: E402
 from vit_ocm_wmsegmentation_amd import synth  # noqa: E402
 
 dev = torch.device("cuda:0")
+PREC = sys.argv[1] if len(sys.argv) > 1 else "bf16x3"
 for arch, p, S in (("vit_small", 16, 224), ("vit_small", 8, 384)):
     model = vits.__dict__[arch](patch_size=p, num_classes=0)
     model.load_state_dict(synth.synth_arch_state_dict(arch, p, seed=0, variant="init"))
-    model = model.eval().to(dev)
+    model = model.eval().to(dev).set_precision(PREC)
     x = synth.synth_tiles(1, S, seed=1).to(dev)
     for name, fn in (("get_intermediate_feat", lambda: model.get_intermediate_feat(x, n=1)),
                      ("get_last_selfattention", lambda: model.get_last_selfattention(x)),
@@ -35,4 +36,4 @@ for arch, p, S in (("vit_small", 16, 224), ("vit_small", 8, 384)):
             fn()
         torch.cuda.synchronize()
         dq = (time.perf_counter() - t1) / n
-        print(f"{arch}/{p} {S}^2 B=1 {name:24s}: {dt * 1e3:7.3f} ms per call (synced), {dq * 1e3:7.3f} ms queued back-to-back", flush=True)
+        print(f"[{PREC}] {arch}/{p} {S}^2 B=1 {name:24s}: {dt * 1e3:7.3f} ms per call (synced), {dq * 1e3:7.3f} ms queued back-to-back", flush=True)

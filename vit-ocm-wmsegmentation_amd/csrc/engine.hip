@@ -342,7 +342,10 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     const int D = h->D, H = h->H, T = batch * n, np = ocm_n_pad_for(h->prec, n);
     const float eps = h->cfg.ln_eps, scale = h->cfg.qk_scale;
     const int pc = h->prec, lnk = ln_kind_of_prec(pc);
-    const bool fuse_ln = linear_resid_ln_supported(D) && g_ocm_knobs[5] != 1;  // knob 5 = 1: separate LayerNorm launches
+    // The fused GEMM + LayerNorm kernel owns full rows (64 x D tiles, D / 128 times the W bytes per workgroup and step):
+    // it pays once there are enough row tiles to occupy the chip (measured: +2 % at T = 12 608; at T = 197, four
+    // workgroups stream all of W each: 1.52 ms per forward against 1.14 ms). Knob 5: 1 = never, 2 = always.
+    const bool fuse_ln = linear_resid_ln_supported(D) && g_ocm_knobs[5] != 1 && (T >= 8192 || g_ocm_knobs[5] == 2);
     if (xn_out) *xn_out = false;
     // y = attn(norm1(x))
     if (!xn_ready) { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, lnk, T, D, eps, s)); }
