@@ -245,6 +245,28 @@ def test_sliding_window_single_rank(dev):
     assert float((maps[:, :, 0] - full).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("name", ["tiny_p8", "vits16_peaked"])
+@pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp32"])
+def test_fused_gemm_layernorm_is_bit_identical(dev, lib, name, precision):
+    """proj / fc2 + residual + the following LayerNorm in one kernel (engine default for T >= 8192 rows, forced here
+    through the development knob) against the separate GEMM and LayerNorm launches: same accumulation order, same
+    two-pass statistics on the same fp32 values -> identical bits in every output."""
+    case = CASES[name]
+    model = build_module(case, dev).set_precision(precision)
+    x = case_inputs(case)[0].to(dev)
+    try:
+        assert lib.ocm_debug_knob(5, 1) == 0  # never fuse
+        f0, a0, q0 = model.get_intermediate_feat(x, 2)
+        l0 = model.get_last_selfattention(x)
+        assert lib.ocm_debug_knob(5, 2) == 0  # always fuse
+        f1, a1, q1 = model.get_intermediate_feat(x, 2)
+        l1 = model.get_last_selfattention(x)
+    finally:
+        lib.ocm_debug_knob(5, 0)
+    for u, v in zip(f0 + a0 + q0 + [l0], f1 + a1 + q1 + [l1]):
+        assert torch.equal(u, v)
+
+
 @pytest.mark.parametrize("size,stride,window", [(200, 32, 96), (160, 32, 128), (130, 32, 96)])
 def test_sliding_window_past_the_slab_edge(dev, size, stride, window):
     """Slabs whose side is not a multiple of the stride / windows wider than 3 strides: the last windows reach past the
