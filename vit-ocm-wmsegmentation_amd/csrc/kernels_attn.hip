@@ -790,6 +790,178 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const char *__restr
     }
 }
 
+
+// Whole-sequence variant of attn_fwd_x3_kernel for N <= 256 (ViT-S/16 and ViT-B/16 at 224^2: N = 197): one workgroup
+// of 8 waves per (batch, head). ALL K and V^T tiles of the head (hi + lo halves: up to 128 KiB) are brought into LDS
+// by one burst of `buffer_load ... lds` DMAs (no staging registers, the chunk swizzle applied on the source address),
+// the V^T columns of padding keys are zeroed in LDS (0 * garbage must not reach the accumulator; the buffer's padding
+// columns are never written by the qkv epilogue), then every wave walks the key tiles of its 32 query rows with no
+// further synchronisation. K / V^T are read once per head instead of once per 128 queries and the per-tile
+// load -> barrier chain of the streaming kernel is gone.
+template <bool WANT_O>
+__global__ __launch_bounds__(512, 2) void attn_small_x3_kernel(const char *__restrict__ Q, const char *__restrict__ Kk,
+                                                               const char *__restrict__ Vt, char *__restrict__ ctx,
+                                                               float *__restrict__ lse2, int N, int npad, int H,
+                                                               float scale2) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int ntiles = (N + 63) >> 6;
+    char *Ks = smem, *Vs = smem + ntiles * 16384;  // per tile: 2 images x 64 rows x 128 B
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int bh = xcd_remap(blockIdx.x, gridDim.x);
+    const int q0 = wave * 32;
+    const char *Qb = Q + (int64_t)bh * npad * 256;
+    const char *Kb = Kk + (int64_t)bh * npad * 256;
+    const char *Vb = Vt + (int64_t)bh * 64 * npad * 4;
+
+    // ---- bulk fill: piece = 1 KiB = 8 LDS rows; K tile kt, image g holds rows (keys) of group g of the head row
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+        typedef __attribute__((address_space(3))) void *lds_ptr;
+        const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, (unsigned)(npad * 256), 0x00020000);
+        const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, (unsigned)(64 * npad * 4), 0x00020000);
+        const int lrow = lane >> 3, slot = lane & 7;
+        // K: ntiles * 2 images * 8 pieces; V^T: the same count. Waves take pieces round-robin.
+        for (int pc = wave; pc < ntiles * 16; pc += 8) {
+            const int kt = pc >> 4, g = (pc >> 3) & 1, rho = (pc & 7) * 8 + lrow;  // row inside the 64-row image
+            const int c = slot ^ ((rho >> 1) & 7);
+            const int key = min(kt * 64 + rho, N - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(Ks + pc * 1024), 16, key * 256 + g * 128 + c * 16, 0, 0, 0);
+            // V^T: row rho = d, the tile's key group g; groups past the padded row length read as zeros (bounds check)
+            const int grp = kt * 2 + g;
+            const int voff = grp * 128 < npad * 4 ? rho * npad * 4 + grp * 128 + c * 16 : 0x7FFFFFF0;
+            if (WANT_O)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(Vs + pc * 1024), 16, voff, 0, 0, 0);
+        }
+    }
+#endif
+    // Q^T as the B operand (overlaps the DMA)
+    bf16x8 qh[4], ql[4];
+    {
+        const char *qp = Qb + (int64_t)min(q0 + r, N - 1) * 256;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const char *p = qp + (s >> 1) * 128 + ((s & 1) * 16 + 8 * h) * 2;
+            qh[s] = *(const bf16x8 *)p;
+            ql[s] = *(const bf16x8 *)(p + 64);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (WANT_O && (N & 63)) {  // zero the V^T halves of the padding keys of the last tile: keys N .. 64*ntiles - 1
+        const int kt = ntiles - 1, first = N - kt * 64;  // first padding key inside the tile
+        for (int i = tid; i < 64 * (64 - first); i += 512) {
+            const int d = i / (64 - first), key = first + i % (64 - first);
+            const int g = key >> 5, kk = key & 31;
+            char *base = Vs + kt * 16384 + g * 8192 + (kk & 7) * 2;
+            *(bf16 *)(base + lds_off(d, kk >> 3)) = (bf16)0.f;        // hi half: chunks 0..3 of the row
+            *(bf16 *)(base + lds_off(d, 4 + (kk >> 3))) = (bf16)0.f;  // lo half: chunks 4..7
+        }
+    }
+    __syncthreads();
+    if (q0 >= N) return;  // no barrier below
+
+    f32x16 O[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[0][e] = O[1][e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int pr = pi_row(r);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const char *Kt = Ks + kt * 16384, *Vtile = Vs + kt * 16384;
+        f32x16 S[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[sub][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const char *kp = Kt + (s >> 1) * 8192 + sub * 32 * 128;
+                const bf16x8 kh = *(const bf16x8 *)(kp + lds_off(pr, (s & 1) * 2 + h));
+                const bf16x8 kl = *(const bf16x8 *)(kp + lds_off(pr, 4 + (s & 1) * 2 + h));
+                S[sub] = mfma32x3(kh, kl, qh[s], ql[s], S[sub]);
+            }
+        }
+        if ((kt + 1) * 64 > N) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (kt * 64 + sub * 32 + key_of_reg(e, h) >= N) S[sub][e] = -INFINITY;
+        }
+        float mx = fmaxf(S[0][0], S[1][0]);
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(S[0][e], S[1][e]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx * scale2);
+        const float alpha = fast_exp2(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = fast_exp2(fmaf(S[sub][e], scale2, -mn));
+                S[sub][e] = p;
+                ps += p;
+            }
+        l = fmaf(l, alpha, ps);
+        if (WANT_O) {
+            if (__any(alpha != 1.0f)) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    O[0][e] *= alpha;
+                    O[1][e] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 ph, pl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float pv = S[sub][8 * s2 + e];
+                        const bf16 t = (bf16)pv;
+                        ph[e] = t;
+                        pl[e] = (bf16)(pv - (float)t);
+                    }
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const char *vp = Vtile + sub * 8192 + db * 32 * 128;
+                        const bf16x8 vh = *(const bf16x8 *)(vp + lds_off(r, 2 * s2 + h));
+                        const bf16x8 vl = *(const bf16x8 *)(vp + lds_off(r, 4 + 2 * s2 + h));
+                        O[db] = mfma32x3(vh, vl, ph, pl, O[db]);
+                    }
+                }
+        }
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const int qrow = q0 + r;
+    if (qrow < N) {
+        if (lse2 && h == 0) lse2[(int64_t)bh * N + qrow] = m + __log2f(lt);
+        if (WANT_O) {
+            const float inv = 1.0f / lt;
+            const int b = bh / H, head = bh - b * H;
+            char *dst = ctx + ((int64_t)b * N + qrow) * (H * 64) * 4 + head * 256;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = O[db][4 * g + e] * inv;
+                    bf16x4 oh, ol;
+                    split4(o, oh, ol);
+                    char *p = dst + db * 128 + (8 * g + 4 * h) * 2;
+                    *(bf16x4 *)p = oh;
+                    *(bf16x4 *)(p + 64) = ol;
+                }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void attn_probs_x3_kernel(const char *__restrict__ Q, const char *__restrict__ Kk,
                                                             const float *__restrict__ lse2, float *__restrict__ attn,
                                                             int N, int npad, float scale2) {
@@ -969,6 +1141,32 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
     const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
     if (prec == 2) {
         if (n_pad % 32) return hipErrorInvalidValue;
+        extern int g_ocm_knobs[8];
+        // Whole-sequence kernel (all K / V^T of a head in LDS, one DMA burst): built, parity-green, and measured SLOWER
+        // than the streaming kernel at ViT-S/16, B = 64 (40.3 us against 34.1 us per launch: 128 KiB of LDS leaves one
+        // workgroup per CU, so nothing overlaps the fill) — kept behind knob 6 = 2 for A/B runs, not dispatched.
+        if (n_tokens <= 256 && g_ocm_knobs[6] == 2) {
+            const int nt = (n_tokens + 63) / 64, lds = nt * 2 * 16384;
+            static unsigned long long optin[2] = {0, 0};
+            int dev = 0;
+            if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+            const void *kern = ctx ? (const void *)attn_small_x3_kernel<true> : (const void *)attn_small_x3_kernel<false>;
+            unsigned long long &mask = optin[ctx ? 1 : 0];
+            if (!(mask >> (dev & 63) & 1)) {
+                if (hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+                    e != hipSuccess)
+                    return e;
+                mask |= 1ull << (dev & 63);
+            }
+            const dim3 g1(batch * heads), b1(512);
+            if (ctx)
+                attn_small_x3_kernel<true><<<g1, b1, lds, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx,
+                                                               lse2, n_tokens, n_pad, heads, scale * LOG2E);
+            else
+                attn_small_x3_kernel<false><<<g1, b1, lds, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx,
+                                                                lse2, n_tokens, n_pad, heads, scale * LOG2E);
+            return hipGetLastError();
+        }
         if (ctx)
             attn_fwd_x3_kernel<true><<<grid, block, 0, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx,
                                                             lse2, n_tokens, n_pad, heads, scale * LOG2E);
