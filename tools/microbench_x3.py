@@ -44,8 +44,6 @@ def main():
     ap.add_argument("--rows", type=int, default=12608)
     ap.add_argument("--dim", type=int, default=384)
     ap.add_argument("--only", default="")
-    ap.add_argument("--stagger", default="0", help="comma list of start-up stagger delays (shader cycles) to sweep")
-    ap.add_argument("--stagger-mode", type=int, default=0)
     a = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -64,10 +62,8 @@ def main():
         odt = torch.float32 if not act_out else {0: torch.bfloat16, 1: torch.float32, 2: torch.int32}[a.prec]
         resid = torch.randn((m, n), generator=g).to(dev)
         ref = None
-        for v, stg in [(v, g_) for v in map(int, a.variants.split(",")) for g_ in map(int, a.stagger.split(","))]:
+        for v in map(int, a.variants.split(",")):
             _lib.check(lib.ocm_debug_knob(0, v))
-            _lib.check(lib.ocm_debug_knob(2, a.stagger_mode))
-            _lib.check(lib.ocm_debug_knob(1, stg))
             out = resid.clone() if epi == 1 else torch.zeros((m, n), dtype=odt, device=dev)
 
             def fn():
@@ -90,9 +86,8 @@ def main():
             else:
                 us = timeit(fn, a.iters)
             fl = 2.0 * m * n * k
-            print(f"{name:14s} variant {v} stagger {stg:6d}: {us:8.2f} us  {fl / us / 1e6:7.1f} TFLOP/s (algorithmic)  bit-identical to v0: {same}")
+            print(f"{name:14s} variant {v}: {us:8.2f} us  {fl / us / 1e6:7.1f} TFLOP/s (algorithmic)  bit-identical to v0: {same}")
     _lib.check(lib.ocm_debug_knob(0, 0))
-    _lib.check(lib.ocm_debug_knob(1, 0))
     if not only or "qkv" in only:  # the real qkv projection (head-major q / k / V^T scatter epilogues), knob 3
         B, N, H = M // 197, 197, D // 64
         x = torch.randn((B * N, D), generator=g).to(dev)

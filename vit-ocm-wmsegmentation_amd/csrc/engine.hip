@@ -91,11 +91,9 @@ extern "C" int ocm_prof_end(double *ms_per_class, int64_t *launches_per_class) {
 }
 
 extern int g_ocm_knobs[8];
-hipError_t ocm_push_stagger();
 extern "C" int ocm_debug_knob(int32_t which, int32_t value) {
     if (which < 0 || which >= 8) return fail(OCM_EINVAL, "knob %d out of range", which);
     g_ocm_knobs[which] = value;
-    if (which == 1 || which == 2) HIP_TRY(ocm_push_stagger());
     return OCM_OK;
 }
 

@@ -34,22 +34,6 @@ __device__ unsigned long long g_stamps[8192 * 8];
 #define STAMP(i) ((void)0)
 #endif
 
-// Development: start-up stagger of co-resident workgroups (tools/microbench_x3.py, knobs 1 and 2). Two workgroups
-// of one kernel that share a CU start together and then run in lockstep — both in their MFMA main loop, both in
-// their VALU epilogue — so the matrix pipe idles while both are in the epilogue. Delaying one of them by about half
-// a tile once, in the first dispatch round, keeps the pair in anti-phase for the rest of the launch (every later
-// workgroup inherits the phase of the slot it is dispatched into).
-__device__ int g_stagger[2] = {0, 0};  // {delay in shader cycles, selection mode}
-__device__ __forceinline__ void stagger_start() {
-    const int delay = g_stagger[0];
-    if (delay <= 0) return;
-    const int b = blockIdx.x, mode = g_stagger[1];
-    const bool hit = mode == 0 ? (b >= 256 && b < 512) : mode == 1 ? ((b & 1) && b < 512) : ((b >> 3 & 1) && b < 512);
-    if (!hit) return;
-    const long long t0 = __builtin_readcyclecounter();
-    while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(16);
-}
-
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
 struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
@@ -514,7 +498,6 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_dma_kernel(const E *__restrict__
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
-    stagger_start();
     STAMP(0);
 #if defined(OCM_ABL) && OCM_ABL == 4  // ablation 4: epilogue only
 #pragma unroll
@@ -553,7 +536,6 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const E *__rest
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
-    stagger_start();
     STAMP(0);
     gemm_mainloop<Cfg, E, SWAP, KSTEPS>(al, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
     STAMP(1);  // prologue + K loop done

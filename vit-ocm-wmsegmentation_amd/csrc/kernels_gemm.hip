@@ -33,13 +33,11 @@ static hipError_t ensure_lds_optin(const void *kern, int bytes, unsigned long lo
     return e;
 }
 
-// development knobs (ocm_debug_knob): [0] GEMM variant override for microbenchmarks, 0 = the shipped choice;
-// [1] start-up stagger in shader cycles, [2] stagger selection mode (gemm_core.h: stagger_start)
+// development knobs (ocm_debug_knob; 0 = shipped behaviour): [0] nn.Linear GEMM variant, [3] qkv GEMM variant,
+// [4] = 2 fused GEMM+LayerNorm on the LDS-DMA loop, [5] LayerNorm fusion 1 = never / 2 = always, [6] = 2 whole-sequence
+// split-bf16 attention. (A start-up stagger of co-resident workgroups was tried through knobs 1 / 2 and removed:
+// no gain at any delay)
 int g_ocm_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-hipError_t ocm_push_stagger() {
-    const int v[2] = {g_ocm_knobs[1], g_ocm_knobs[2]};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), v, sizeof v);
-}
 
 static inline bool big_tiles_pay(int M, int N, int K) {
     return K >= 768 && N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) >= 512;
@@ -181,7 +179,9 @@ static hipError_t launch_gemm_dma(const E *a, int64_t lda, const E *w, int64_t l
                                   hipStream_t s) {
     if (K % Elem<E>::KROW) return hipErrorInvalidValue;
     switch (K / Elem<E>::KROW) {
+        case 6: return launch_gemm_dma_ks<Cfg, E, 6, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
         case 12: return launch_gemm_dma_ks<Cfg, E, 12, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
+        case 24: return launch_gemm_dma_ks<Cfg, E, 24, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
         case 48: return launch_gemm_dma_ks<Cfg, E, 48, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
         default: break;
     }
@@ -212,6 +212,10 @@ static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, 
         // they stay on the register-staged loop.
         if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512)
             return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
+    }
+    if constexpr (Elem<E>::MODE == 0) {  // development A/B: the LDS-DMA loop on single-bf16 operands (knob 0 = 4 / 7)
+        if (g_ocm_knobs[0] == 4 && N % 128 == 0) return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
+        if (g_ocm_knobs[0] == 7 && N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 2>(a, K, w, K, M, N, K, epi, s);
     }
 reg_staged:
     if constexpr (Elem<E>::MODE == 0)
@@ -429,7 +433,8 @@ struct EpiQK {
         constexpr int RSTEP = NT / CPR, ITERS = BM / RSTEP;
         const int col = (threadIdx.x % CPR) * 8, row0 = threadIdx.x / CPR;
         const int n = n0 + col;
-        const int which = n / D, rem = n - which * D, head = rem / hd, d = rem - head * hd;
+        const int which = n / D, rem = n - which * D;
+        const int head = hd == 64 ? rem >> 6 : rem / hd, d = rem - head * hd;
         int m = m0 + row0;
         int b = m / ntok, t = m - b * ntok;
         E *base = which ? k : q;
@@ -485,7 +490,8 @@ struct EpiVt {
         const int rem0 = n0 - 2 * D;
 #pragma unroll 4
         for (int row = threadIdx.x / BM; row < BN; row += RS) {
-            const int rem = rem0 + row, head = rem / hd, d = rem - head * hd;
+            const int rem = rem0 + row;
+            const int head = hd == 64 ? rem >> 6 : rem / hd, d = rem - head * hd;  // no integer division on the hot path
             const float v = C[row * BM + col];
             if (vt) store_act1((E *)nullptr, (char *)vt + ((int64_t)(b * H + head) * 64 + d) * npad * (int)sizeof(E), t, v);
             if (qkv32) qkv32[((((int64_t)2 * B + b) * H + head) * ntok + t) * hd + d] = v;
@@ -505,7 +511,6 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader<E> al, const E *
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
-    stagger_start();
     if (n0 < 2 * D) {  // workgroup-uniform
         gemm_mainloop<Cfg, E, false, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
         run_epilogue<Cfg, false>(acc, smem, eqk, m0, n0);
