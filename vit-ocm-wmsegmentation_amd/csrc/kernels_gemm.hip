@@ -210,6 +210,8 @@ static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, 
         // (ViT-S/16, B = 64, same box, alternating runs) fc1 62 -> 57 us; the 64x128 shapes (proj, fc2) and the qkv
         // projection measure the same either way (their stand-alone gains of 10 % do not survive cold operands), so
         // they stay on the register-staged loop.
+        if (big_tiles_pay(M, N, K))  // ViT-B at 384^2: 256x256 tiles, one 8-wave workgroup per CU (fc1 1020 -> 944 us)
+            return launch_gemm_dma<Cfg256x256, E, 2>(a, K, w, K, M, N, K, epi, s);
         if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512)
             return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
     }
