@@ -616,8 +616,10 @@ __global__ __launch_bounds__(256) void attn_probs_f32_kernel(const float *__rest
 // 32 keys. Every product runs as three bf16 MFMAs (hi*hi + hi*lo + lo*hi), P is split in registers. An LDS tile of
 // 64 keys is two images (one per 128-byte group) of [64 rows][128 B] with the usual chunk swizzle, so the
 // fragment reads are the conflict-free pattern of the bf16 kernel and staging is a byte copy.
-template <bool WANT_O>
-__global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const char *__restrict__ Q, const char *__restrict__ Kk,
+// NW waves (4 or 8) of 32 queries share the K / V^T tiles: 8 waves halve the L2 -> LDS bytes per query at the same
+// waves per CU (one 8-wave workgroup instead of two 4-wave ones; N = 2305: 440 -> measured below us per launch).
+template <bool WANT_O, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_fwd_x3_kernel(const char *__restrict__ Q, const char *__restrict__ Kk,
                                                              const char *__restrict__ Vt, char *__restrict__ ctx,
                                                              float *__restrict__ lse2, int N, int npad, int H,
                                                              float scale2) {
@@ -627,7 +629,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const char *__restr
     const int r = lane & 31, h = lane >> 5;
     int qblk, bh;
     xcd_remap2(qblk, bh);
-    const int q0 = (qblk * 4 + wave) * 32;
+    const int q0 = (qblk * NW + wave) * 32;
+    constexpr int NT = NW * 64, CH = 1024 / NT;  // 16-B chunks per thread per tile and operand
     const bool active = q0 < N;  // wave-uniform
     const char *Qb = Q + (int64_t)bh * npad * 256;
     const char *Kb = Kk + (int64_t)bh * npad * 256;
@@ -645,12 +648,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const char *__restr
         }
     }
 
-    // staging: 1024 K chunks + 1024 V^T chunks of 16 B per tile, 256 threads -> 4 + 4 each
-    f32x4 rk[4], rv[4];
+    // staging: 1024 K chunks + 1024 V^T chunks of 16 B per tile, NT threads -> CH + CH each
+    f32x4 rk[CH], rv[CH];
     auto issue = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int qd = tid + 256 * i, row = qd >> 4, c16 = qd & 15;  // row: key (K) or d (V^T); 16 chunks per row
+        for (int i = 0; i < CH; ++i) {
+            const int qd = tid + NT * i, row = qd >> 4, c16 = qd & 15;  // row: key (K) or d (V^T); 16 chunks per row
             const int key = min(kt * 64 + row, N - 1);
             rk[i] = *(const f32x4 *)(Kb + (int64_t)key * 256 + c16 * 16);
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -670,8 +673,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_x3_kernel(const char *__restr
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int qd = tid + 256 * i, row = qd >> 4, c16 = qd & 15;
+        for (int i = 0; i < CH; ++i) {
+            const int qd = tid + NT * i, row = qd >> 4, c16 = qd & 15;
             const int o = buf * 16384 + (c16 >> 3) * 8192 + lds_off(row, c16 & 7);
             *(f32x4 *)(Ks + o) = rk[i];
             *(f32x4 *)(Vs + o) = rv[i];
@@ -1167,12 +1170,18 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
                                                                 lse2, n_tokens, n_pad, heads, scale * LOG2E);
             return hipGetLastError();
         }
-        if (ctx)
-            attn_fwd_x3_kernel<true><<<grid, block, 0, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx,
-                                                            lse2, n_tokens, n_pad, heads, scale * LOG2E);
-        else
-            attn_fwd_x3_kernel<false><<<grid, block, 0, s>>>((const char *)q, (const char *)k, (const char *)vt,
-                                                             (char *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+        // long sequences: 8 waves per workgroup share each K / V^T tile (half the L2 -> LDS traffic per query)
+        const bool wide = (n_tokens > 1024 && g_ocm_knobs[7] != 1) || g_ocm_knobs[7] == 2;
+        const dim3 grid8((qtiles + 7) / 8, batch * heads), block8(512);
+#define OCM_X3_ATTN(WO, NW_, G, B_)                                                                                      \
+    attn_fwd_x3_kernel<WO, NW_><<<G, B_, 0, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx, lse2, \
+                                                 n_tokens, n_pad, heads, scale * LOG2E)
+        if (wide) {
+            if (ctx) OCM_X3_ATTN(true, 8, grid8, block8); else OCM_X3_ATTN(false, 8, grid8, block8);
+        } else {
+            if (ctx) OCM_X3_ATTN(true, 4, grid, block); else OCM_X3_ATTN(false, 4, grid, block);
+        }
+#undef OCM_X3_ATTN
         return hipGetLastError();
     }
     if (ctx)
