@@ -204,12 +204,21 @@ static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, 
             case 6: if (N % 128 == 0) return launch_gemm_dma<Cfg256x128, E, 2>(a, K, w, K, M, N, K, epi, s); break;
             case 7: if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 2>(a, K, w, K, M, N, K, epi, s); break;
             case 8: if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 3>(a, K, w, K, M, N, K, epi, s); break;
+            case 9: if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 4>(a, K, w, K, M, N, K, epi, s); break;
+            case 10: if (N % 64 == 0) return launch_gemm_dma<Cfg64x64, E, 4>(a, K, w, K, M, N, K, epi, s); break;
             default: break;
         }
         // Split-bf16 operands, >= 512 tiles of 128x128 (fc1): LDS-DMA staging, two workgroups per CU. Inside the forward
         // (ViT-S/16, B = 64, same box, alternating runs) fc1 62 -> 57 us; the 64x128 shapes (proj, fc2) and the qkv
         // projection measure the same either way (their stand-alone gains of 10 % do not survive cold operands), so
         // they stay on the register-staged loop.
+        // Few rows (the reference's one-tile-per-call loops, M = 197 .. 785): everything is L2-resident and a launch is a
+        // handful of workgroups, so the LDS-DMA loop's shorter prologue shows (stand-alone, M = 197: fc1 9.4 -> 7.9 us,
+        // fc2 23.1 -> 16.7 us on 64x64 tiles with a 4-deep ring, proj 8.3 -> 7.6 us)
+        if (M <= 1024 && g_ocm_knobs[0] == 0) {
+            if (K >= 1024 && N % 64 == 0) return launch_gemm_dma<Cfg64x64, E, 4>(a, K, w, K, M, N, K, epi, s);
+            if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 2>(a, K, w, K, M, N, K, epi, s);
+        }
         if (big_tiles_pay(M, N, K))  // ViT-B at 384^2: 256x256 tiles, one 8-wave workgroup per CU (fc1 1020 -> 944 us)
             return launch_gemm_dma<Cfg256x256, E, 2>(a, K, w, K, M, N, K, epi, s);
         if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512)
