@@ -88,7 +88,9 @@ struct RowLoader {
     typedef typename Elem<E>::Chunk Raw;
     __device__ __forceinline__ Handle row(int m) const { return (const char *)A + (int64_t)m * lda * (int)sizeof(E); }
     // chunk c of K step t
-    __device__ __forceinline__ Raw load(Handle h, int t, int c) const { return *(const Raw *)(h + t * 128 + c * 16); }
+    __device__ __forceinline__ Raw load(Handle h, int t, int c) const {
+        return *(const Raw *)(h + t * 128 + c * 16);
+    }
     __device__ __forceinline__ static Raw finish(const Raw &r, int) { return r; }
 };
 

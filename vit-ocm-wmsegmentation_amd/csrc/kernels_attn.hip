@@ -29,6 +29,7 @@
 #include "launch.h"
 
 #define LOG2E 1.4426950408889634f
+int ocm_wt_mask();  // kernels_gemm.hip
 
 template <bool WANT_O>
 // compiled for three waves per SIMD (<= 168 registers, no spills): the softmax VALU work of one wave overlaps the
@@ -622,7 +623,7 @@ template <bool WANT_O, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_x3_kernel(const char *__restrict__ Q, const char *__restrict__ Kk,
                                                              const char *__restrict__ Vt, char *__restrict__ ctx,
                                                              float *__restrict__ lse2, int N, int npad, int H,
-                                                             float scale2) {
+                                                             float scale2, int wt) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 16384];  // K[2] | Vt[2], 16 KiB each
     char *Ks = smem, *Vs = smem + 2 * 16384;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -786,8 +787,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_x3_kernel(const char *__r
                     bf16x4 oh, ol;
                     split4(o, oh, ol);
                     char *p = dst + db * 128 + (8 * g + 4 * h) * 2;
-                    *(bf16x4 *)p = oh;
-                    *(bf16x4 *)(p + 64) = ol;
+                    if (wt) {  // write-through: the context rows are consumed by another kernel, not by this one
+                        const f32x2 dh = __builtin_bit_cast(f32x2, oh), dl = __builtin_bit_cast(f32x2, ol);
+                        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(dh) : "memory");
+                        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + 64), "v"(dl) : "memory");
+                    } else {
+                        *(bf16x4 *)p = oh;
+                        *(bf16x4 *)(p + 64) = ol;
+                    }
                 }
         }
     }
@@ -1175,7 +1182,7 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
         const dim3 grid8((qtiles + 7) / 8, batch * heads), block8(512);
 #define OCM_X3_ATTN(WO, NW_, G, B_)                                                                                      \
     attn_fwd_x3_kernel<WO, NW_><<<G, B_, 0, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx, lse2, \
-                                                 n_tokens, n_pad, heads, scale * LOG2E)
+                                                 n_tokens, n_pad, heads, scale * LOG2E, (ocm_wt_mask() >> 4) & 1)
         if (wide) {
             if (ctx) OCM_X3_ATTN(true, 8, grid8, block8); else OCM_X3_ATTN(false, 8, grid8, block8);
         } else {

@@ -38,6 +38,12 @@ static hipError_t ensure_lds_optin(const void *kern, int bytes, unsigned long lo
 // split-bf16 attention. (A start-up stagger of co-resident workgroups was tried through knobs 1 / 2 and removed:
 // no gain at any delay)
 int g_ocm_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// Write-through (sc1) stores of streaming activation outputs, as a bit mask: 1 = nn.Linear activation outputs (fc1's
+// hidden tensor), 2 = q / k of the qkv projection, 4 = xn of the fused LayerNorm, 16 = attention context, 32 = x of the fused GEMM + LayerNorm; non-temporal loads of
+// the A rows of the full-row tiles were tried too (flat). Shipped: 1 | 2 | 32
+// (fc1 57.0 -> 54.2 us and +2.2 % end to end in alternating runs; qkv -0.7 us; x +0.6 % end to end; xn flat; the 8-byte
+// context stores get slower, 32 -> 39 us). Knob 1: 0 = shipped mask, -1 = none, any other value = that mask.
+int ocm_wt_mask() { return g_ocm_knobs[1] == 0 ? 35 : g_ocm_knobs[1] < 0 ? 0 : g_ocm_knobs[1]; }
 
 static inline bool big_tiles_pay(int M, int N, int K) {
     return K >= 768 && N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) >= 512;
@@ -56,6 +62,24 @@ __device__ __forceinline__ void store_act(sp32 *, char *rowp, int col, const f32
     split8(v0, v1, hi, lo);
     *(bf16x8 *)(rowp + sp_off(col)) = hi;
     *(bf16x8 *)(rowp + sp_off(col) + 64) = lo;
+}
+// Write-through (sc1) 16-byte store: the line leaves the XCD's L2 instead of staying in it. For outputs that are far
+// larger than the L2 and are not re-read by this kernel (fc1's 77 MB hidden tensor), plain stores evict the operands
+// the other workgroups of the XCD are still streaming. The trailing s_nop covers the store-data hazard hipcc cannot
+// see inside an asm statement.
+__device__ __forceinline__ void store16_wt(void *p, const bf16x8 &v) {
+    const f32x4 d = __builtin_bit_cast(f32x4, v);
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
+}
+__device__ __forceinline__ void store_act_wt(sp32 *, char *rowp, int col, const f32x4 &v0, const f32x4 &v1) {
+    bf16x8 hi, lo;
+    split8(v0, v1, hi, lo);
+    store16_wt(rowp + sp_off(col), hi);
+    store16_wt(rowp + sp_off(col) + 64, lo);
+}
+template <class OE>
+__device__ __forceinline__ void store_act_wt(OE *t, char *rowp, int col, const f32x4 &v0, const f32x4 &v1) {
+    store_act(t, rowp, col, v0, v1);
 }
 // one element
 __device__ __forceinline__ void store_act1(bf16 *, char *rowp, int col, float v) { *(bf16 *)(rowp + col * 2) = (bf16)v; }
@@ -82,6 +106,7 @@ struct EpiLinear {
     void *out;
     int M, N;
     int64_t ldo;
+    int wt = 0;  // activation outputs with write-through (sc1) stores
     template <class Cfg>
     __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
@@ -123,7 +148,10 @@ struct EpiLinear {
                         }
                     }
                 }
-                store_act((OE *)nullptr, (char *)out + (int64_t)m * ldo * (int)sizeof(OE), n, v0, v1);
+                if (wt)
+                    store_act_wt((OE *)nullptr, (char *)out + (int64_t)m * ldo * (int)sizeof(OE), n, v0, v1);
+                else
+                    store_act((OE *)nullptr, (char *)out + (int64_t)m * ldo * (int)sizeof(OE), n, v0, v1);
             }
         }
     }
@@ -196,6 +224,7 @@ static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, 
                                      int N, int K, hipStream_t s) {
     RowLoader<E> al{a, K};
     EpiLinear<MODE, E> epi{bias, resid, out, M, N, N};
+    epi.wt = ocm_wt_mask() & 1;
     if constexpr (Elem<E>::MODE == 2) {
         switch (g_ocm_knobs[0]) {  // development: force a variant (tools/microbench_x3.py)
             case -1: goto reg_staged;
@@ -306,6 +335,7 @@ struct EpiResidLN {
     void *xn;           // [M][D] OE: LayerNorm(x) for the next GEMM
     int M;
     float eps;
+    int wt = 0;         // bit 0: xn with write-through stores
     template <class Cfg>
     __device__ __forceinline__ void run(const float *C, int m0, int) const {
         constexpr int BM = Cfg::BM, NT = Cfg::NT, NV = D_ / 128;
@@ -329,7 +359,10 @@ struct EpiResidLN {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 v[i] += *(const f32x4 *)(C + row * D_ + sub * 4 + i * 128);
-                *(f32x4 *)(x + (int64_t)m * D_ + sub * 4 + i * 128) = v[i];
+                if (wt & 2)
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(x + (int64_t)m * D_ + sub * 4 + i * 128), "v"(v[i]) : "memory");
+                else
+                    *(f32x4 *)(x + (int64_t)m * D_ + sub * 4 + i * 128) = v[i];
                 s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
 #pragma unroll
@@ -363,8 +396,14 @@ struct EpiResidLN {
                 } else {
                     bf16x4 hi, lo;
                     split4(o, hi, lo);
-                    *(bf16x4 *)(rowp + sp_off(c)) = hi;
-                    *(bf16x4 *)(rowp + sp_off(c) + 64) = lo;
+                    if (wt & 1) {
+                        const f32x2 dh = __builtin_bit_cast(f32x2, hi), dl = __builtin_bit_cast(f32x2, lo);
+                        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(rowp + sp_off(c)), "v"(dh) : "memory");
+                        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(rowp + sp_off(c) + 64), "v"(dl) : "memory");
+                    } else {
+                        *(bf16x4 *)(rowp + sp_off(c)) = hi;
+                        *(bf16x4 *)(rowp + sp_off(c) + 64) = lo;
+                    }
                 }
             }
         }
@@ -377,6 +416,7 @@ static hipError_t launch_resid_ln_d(const E *a, const E *w, const float *bias, c
                                     hipStream_t s) {
     typedef GemmCfg<64, D_, 2, 4> Cfg;  // 8 waves, wave tile 32 x D/4
     EpiResidLN<E, D_> epi{bias, resid, x, gamma, beta, xn, M, eps};
+    epi.wt = ((ocm_wt_mask() >> 2) & 1) | ((ocm_wt_mask() >> 4) & 2);  // mask 4: xn, mask 32: x
     if constexpr (Elem<E>::MODE == 2) {
         // One 8-wave workgroup per CU: the two-step register prefetch hides more latency than a two-stage LDS-DMA ring
         // (fc2 + LayerNorm at ViT-S/16, B = 64: 72 us against 89 us), and a third stage does not fit next to the
@@ -434,6 +474,7 @@ struct EpiQK {
     E *q, *k;      // head-major operand copies (head_dim 64 only), or nullptr
     float *qkv32;  // optional (3,B,H,N,hd) fp32, or nullptr
     int M, ntok, npad, H, D, B, hd;
+    int wt = 0;  // write-through stores for q / k
     // C is [BM][BN] (rows = tokens). One lane moves 8 consecutive head-dim columns of one token. A lane keeps its
     // column chunk for the whole tile and walks the rows in constant steps, so which / head / d are computed once
     // and (image b, token t) advance incrementally: no integer division per chunk.
@@ -458,7 +499,10 @@ struct EpiQK {
             if (base) {
                 char *rowp = (char *)base + ((int64_t)(b * H + head) * npad + t) * 64 * (int)sizeof(E);
                 if (Elem<E>::EPW == 8) {
-                    store_act((E *)nullptr, rowp, d, v0, v1);
+                    if (wt)
+                        store_act_wt((E *)nullptr, rowp, d, v0, v1);
+                    else
+                        store_act((E *)nullptr, rowp, d, v0, v1);
                 } else {
                     store_act((E *)nullptr, rowp, d, v0, v0);
                     store_act((E *)nullptr, rowp, d + 4, v1, v1);
@@ -605,6 +649,7 @@ static hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, 
     if (head_dim % 8) return hipErrorInvalidValue;                      // a lane's 8 columns stay inside one head
     RowLoader<E> al{a, D};
     EpiQK<E> eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch, head_dim};
+    eqk.wt = (ocm_wt_mask() >> 1) & 1;
     EpiVt<E> ev{bias, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch, head_dim, want_v};
     if constexpr (Elem<E>::MODE == 0)
         if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_cfg<Cfg256x256, E>(al, w, M, D, eqk, ev, s);
