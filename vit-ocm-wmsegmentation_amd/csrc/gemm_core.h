@@ -325,18 +325,19 @@ __device__ __forceinline__ void wait_vm_steps(int younger) {
 
 // CNT buffer_load ... lds instructions of one wave: instruction j fills LDS rows (j * NW + wave) * 8 .. + 7 of the image
 // at `img` from the per-lane byte offsets voff[j] (+ soff, the K step) of the buffer `rs`.
-template <int CNT, int NW>
+template <int CNT, int NW, int AUX = 0>
 __device__ __forceinline__ void dma_rows(__amdgpu_buffer_rsrc_t rs, char *img, const int (&voff)[CNT], int wave,
                                          int soff) {
 #if defined(__HIP_DEVICE_COMPILE__)  // hipcc's HOST pass mis-handles a second instantiation context of this builtin
     typedef __attribute__((address_space(3))) void *lds_ptr;
 #pragma unroll
     for (int j = 0; j < CNT; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(img + (j * NW + wave) * 1024), 16, voff[j], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(img + (j * NW + wave) * 1024), 16, voff[j], soff, 0, AUX);
 #endif
 }
 
-template <class Cfg, class E, bool SWAP, int KSTEPS, int NSTAGE>
+// A_AUX: cache-policy bits of the A operand's DMA loads (2 = nt: streamed activations should not evict the weights)
+template <class Cfg, class E, bool SWAP, int KSTEPS, int NSTAGE, int A_AUX = 0>
 __device__ __forceinline__ void gemm_mainloop_dma(const E *__restrict__ A, int64_t lda, const E *__restrict__ W,
                                                   int64_t ldw, int m0, int n0, int M, int N, int K, char *smem,
                                                   f32x16 (&acc)[Cfg::TM][Cfg::TN], const float *__restrict__ bias) {
@@ -376,7 +377,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const E *__restrict__ A, int64
 #define OCM_DMA_ISSUE(t, buf)                                                   \
     do {                                                                        \
         char *st_ = smem + (buf) * STAGE;                                       \
-        dma_rows<A_I, NW>(rsA, st_, voffA, wave, (t) * 128);                    \
+        dma_rows<A_I, NW, A_AUX>(rsA, st_, voffA, wave, (t) * 128);             \
         dma_rows<B_I, NW>(rsB, st_ + BM * 128, voffB, wave, (t) * 128);         \
     } while (0)
     auto compute = [&](int buf) {
@@ -491,7 +492,7 @@ __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::T
 }
 
 // LDS-DMA variant of gemm_kernel for row-major A (activations): dynamic LDS = NSTAGE * (BM + BN) * 128 bytes.
-template <class Cfg, class E, bool SWAP, int KSTEPS, int NSTAGE, class Epi>
+template <class Cfg, class E, bool SWAP, int KSTEPS, int NSTAGE, class Epi, int A_AUX = 0>
 __global__ __launch_bounds__(Cfg::NT) void gemm_dma_kernel(const E *__restrict__ A, int64_t lda, const E *__restrict__ W,
                                                            int64_t ldw, int M, int N, int K, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_dma_kernel(const E *__restrict__
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = (float)(threadIdx.x + e);
 #else
-    gemm_mainloop_dma<Cfg, E, SWAP, KSTEPS, NSTAGE>(A, lda, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
+    gemm_mainloop_dma<Cfg, E, SWAP, KSTEPS, NSTAGE, A_AUX>(A, lda, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
 #endif
     STAMP(1);
 #if defined(OCM_ABL) && OCM_ABL == 3  // ablation 3: no epilogue (accumulators kept live)

@@ -40,7 +40,8 @@ static hipError_t ensure_lds_optin(const void *kern, int bytes, unsigned long lo
 int g_ocm_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 // Write-through (sc1) stores of streaming activation outputs, as a bit mask: 1 = nn.Linear activation outputs (fc1's
 // hidden tensor), 2 = q / k of the qkv projection, 4 = xn of the fused LayerNorm, 16 = attention context, 32 = x of the fused GEMM + LayerNorm; non-temporal loads of
-// the A rows of the full-row tiles were tried too (flat). Shipped: 1 | 2 | 32
+// the A rows of the full-row tiles (flat) and the nt policy on fc1's A-operand DMA (53.5 -> 63.4 us: the 12-fold reuse
+// of an A panel suffers) were tried too. Shipped: 1 | 2 | 32
 // (fc1 57.0 -> 54.2 us and +2.2 % end to end in alternating runs; qkv -0.7 us; x +0.6 % end to end; xn flat; the 8-byte
 // context stores get slower, 32 -> 39 us). Knob 1: 0 = shipped mask, -1 = none, any other value = that mask.
 int ocm_wt_mask() { return g_ocm_knobs[1] == 0 ? 35 : g_ocm_knobs[1] < 0 ? 0 : g_ocm_knobs[1]; }
@@ -192,12 +193,12 @@ static hipError_t launch_gemm(const ALoad &al, const E *w, int64_t ldw, int M, i
 template <class Cfg, class E, int KSTEPS, int NSTAGE, class Epi>
 static hipError_t launch_gemm_dma_ks(const E *a, int64_t lda, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
                                      hipStream_t s) {
-    auto kern = gemm_dma_kernel<Cfg, E, false, KSTEPS, NSTAGE, Epi>;
     constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds the CU");
+    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
+    auto kern = gemm_dma_kernel<Cfg, E, false, KSTEPS, NSTAGE, Epi>;
     static unsigned long long optin = 0;
     if (hipError_t e = ensure_lds_optin((const void *)kern, LDS, optin); e != hipSuccess) return e;
-    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
     kern<<<dim3(tiles), dim3(Cfg::NT), LDS, s>>>(a, lda, w, ldw, M, N, K, epi);
     return hipGetLastError();
 }
