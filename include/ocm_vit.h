@@ -302,6 +302,9 @@ int ocm_op_stitch_image_u8(const float *image, int64_t stride_c, int64_t stride_
 int ocm_op_weighted_u8(const float *heat, const uint8_t *img, int64_t count, void *scratch, uint8_t *result,
                        uint8_t *att_u8, uint64_t *hist_result, uint64_t *hist_att, void *stream);
 
+/* 256-bin histogram of a uint8 image (input of the Otsu levels when the image arrives as uint8). */
+int ocm_op_histogram_u8(const uint8_t *img, int64_t count, uint64_t *hist256, void *stream);
+
 /* eval.py:144,158 — scipy.ndimage.median_filter(map, size): size x size footprint, mode "reflect", upper median.
  * (T,h,w) fp32 -> (T,h,w); src != dst. Pinned against scipy (tests/golden/median.npz). */
 int ocm_op_median_filter(const float *src, float *dst, int32_t tiles, int32_t h, int32_t w, int32_t size, void *stream);

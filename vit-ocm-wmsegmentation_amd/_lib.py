@@ -146,6 +146,7 @@ SIGNATURES = {
     "ocm_op_pixel_shuffle": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_stitch_image_u8": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "ocm_op_weighted_u8": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ocm_op_histogram_u8": (C.c_int, [_vp, _i64, _vp, _vp]),
     "ocm_op_median_filter": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_downscale_centre": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_im2col3x3": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -785,6 +785,13 @@ extern "C" int ocm_op_weighted_u8(const float *heat, const uint8_t *img, int64_t
     return OCM_OK;
 }
 
+extern "C" int ocm_op_histogram_u8(const uint8_t *img, int64_t count, uint64_t *hist256, void *stream) {
+    if (!img || !hist256) return fail(OCM_EINVAL, "null argument");
+    if (count <= 0) return fail(OCM_EINVAL, "bad count");
+    HIP_TRY(launch_histogram_u8(img, (size_t)count, (unsigned long long *)hist256, (hipStream_t)stream));
+    return OCM_OK;
+}
+
 extern "C" int ocm_op_median_filter(const float *src, float *dst, int32_t tiles, int32_t h, int32_t w, int32_t size,
                                     void *stream) {
     if (!src || !dst || src == dst) return fail(OCM_EINVAL, "null or aliased argument");

@@ -491,3 +491,23 @@ hipError_t launch_downscale_centre(const float *src, float *dst, int tiles, int 
     downscale_centre_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(src, dst, h, w, f, total);
     return hipGetLastError();
 }
+
+// 256-bin histogram of a uint8 image (the Otsu levels of threshold() are computed from it on the host)
+__global__ __launch_bounds__(256) void histogram_u8_kernel(const uint8_t *__restrict__ img, size_t count,
+                                                           unsigned long long *hist) {
+    __shared__ unsigned int lh[256];
+    lh[threadIdx.x] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) atomicAdd(&lh[img[i]], 1u);
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], (unsigned long long)lh[threadIdx.x]);
+}
+
+hipError_t launch_histogram_u8(const uint8_t *img, size_t count, unsigned long long *hist256, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(hist256, 0, 256 * sizeof(unsigned long long), s);
+    if (e != hipSuccess) return e;
+    size_t blocks = (count + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    histogram_u8_kernel<<<dim3((unsigned)blocks), dim3(256), 0, s>>>(img, count, hist256);
+    return hipGetLastError();
+}

@@ -85,6 +85,7 @@ hipError_t launch_stitch_image_u8(const float *image, int64_t sc, int64_t sy, in
                                   hipStream_t s);
 hipError_t launch_weighted_u8(const float *heat, const uint8_t *img, size_t count, float *part, uint8_t *result,
                               uint8_t *att_u8, unsigned long long *hist_res, unsigned long long *hist_att, hipStream_t s);
+hipError_t launch_histogram_u8(const uint8_t *img, size_t count, unsigned long long *hist256, hipStream_t s);
 hipError_t launch_median_filter(const float *src, float *dst, int tiles, int h, int w, int k, hipStream_t s);
 hipError_t launch_downscale_centre(const float *src, float *dst, int tiles, int h, int w, int f, hipStream_t s);
 

@@ -295,9 +295,9 @@ class VisionTransformer(nn.Module):
         if self._gray_fold:
             hy["in_chans"] = 1
         eng = ent[0] if ent is not None else Engine(device=device, precision=_lib.PRECISIONS[self._precision], **hy)
-        have = set()
+        have, keep = set(), []
         for name, p in named:
-            eng.set_param(name, p)
+            eng.set_param(name, p, keep)
             have.add(name)
         zeros = {}
         for i, blk in enumerate(self.blocks):  # qkv_bias=False etc.: the engine always adds a bias
@@ -306,9 +306,10 @@ class VisionTransformer(nn.Module):
                 key = f"blocks.{i}.{sub}.bias"
                 if key not in have:
                     z = zeros.setdefault(lin.out_features, torch.zeros(lin.out_features, device=device))
-                    eng.set_param(key, z)
+                    eng.set_param(key, z, keep)
         if self.patch_embed.proj.bias is None:
-            eng.set_param("patch_embed.proj.bias", torch.zeros(self.embed_dim, device=device))
+            eng.set_param("patch_embed.proj.bias", torch.zeros(self.embed_dim, device=device), keep)
+        eng.flush(keep)  # one synchronisation per load, not one per parameter
         self._engines[device] = (eng, sig)
         return eng
 

@@ -95,13 +95,23 @@ class Engine:
             pass
 
     # ---- parameters -------------------------------------------------------------------------
-    def set_param(self, name, tensor):
-        """Upload one state_dict entry (reference key name, reference layout)."""
+    def set_param(self, name, tensor, keep=None):
+        """Upload one state_dict entry (reference key name, reference layout). The source may be a temporary copy that
+        must outlive the asynchronous cast kernel: pass a list as `keep` to collect such temporaries and synchronise ONCE
+        after the last upload (`Engine.flush(keep)`), otherwise the stream is synchronised here."""
         t = tensor.detach().to(device=self.device, dtype=torch.float32).contiguous()
         with torch.cuda.device(self.device):
             check(self.lib.ocm_vit_set_param(self._h, name.encode(), _p(t), t.numel(), _stream()))
-            # the source may be a temporary: keep it alive until the cast kernel has run
+            if keep is None:
+                torch.cuda.current_stream().synchronize()
+            else:
+                keep.append(t)
+
+    def flush(self, keep):
+        """Wait for the uploads whose sources `keep` holds, then let them go."""
+        with torch.cuda.device(self.device):
             torch.cuda.current_stream().synchronize()
+        keep.clear()
 
     def n_tokens(self, tile_h, tile_w):
         return (tile_h // self.p) * (tile_w // self.p) + 1

@@ -138,7 +138,7 @@ def threshold(img_u8, heat, hist_img=None, as_numpy=False):
       result = (img * attention / max(attention)).astype(uint8), attention = min_max_normalize(heat)     :42-46
       th  = cv2 Otsu mask of result (:53), th2 = img > skimage Otsu level of img (:55-58), th3 = cv2 Otsu mask of
       attention * 255 (:60). The Otsu levels are 256-step scalar loops over device histograms, evaluated on the host."""
-    from .utils import _otsu_from_hist, skimage_otsu_from_hist
+    from .utils import _otsu_from_hist, histogram_u8, skimage_otsu_from_hist
     if not (heat.is_cuda and heat.dtype == torch.float32 and img_u8.is_cuda and img_u8.dtype == torch.uint8):
         raise RuntimeError("threshold needs a uint8 image and a float32 heat map on a HIP device (no CPU fallback)")
     if tuple(img_u8.shape) != tuple(heat.shape):
@@ -146,7 +146,7 @@ def threshold(img_u8, heat, hist_img=None, as_numpy=False):
     heat, img_u8 = heat.contiguous(), img_u8.contiguous()
     lib, dev, n = _lib.load(), heat.device, heat.numel()
     if hist_img is None:
-        hist_img = torch.bincount(img_u8.reshape(-1).to(torch.int64), minlength=256)
+        hist_img = histogram_u8(img_u8)
     res = torch.empty(heat.shape, dtype=torch.uint8, device=dev)
     att = torch.empty(heat.shape, dtype=torch.uint8, device=dev)
     masks = torch.empty((3,) + tuple(heat.shape), dtype=torch.uint8, device=dev)

@@ -78,6 +78,16 @@ def skimage_otsu_from_hist(hist_dev):
     return int(centers[int(np.argmax(variance12))])
 
 
+def histogram_u8(img_u8):
+    """256-bin int64 histogram of a uint8 HIP tensor (ocm_op_histogram_u8)."""
+    _require_hip(img_u8, "img")
+    img_u8 = img_u8.contiguous()
+    hist = torch.empty(256, dtype=torch.int64, device=img_u8.device)
+    with torch.cuda.device(img_u8.device):
+        _lib.check(_lib.load().ocm_op_histogram_u8(_p(img_u8), img_u8.numel(), _p(hist), _stream()))
+    return hist
+
+
 def image_to_gray_u8(img):
     """transform(img.squeeze(0)).convert("L") of eval.py:166 on device: (C,H,W) or (1,C,H,W) float tensor in
     [0,1] with C in {1,3} -> ((H,W) uint8 tensor, 256-bin int64 histogram)."""
@@ -112,7 +122,7 @@ def threshold(img, attention, output_directory="", save=False, name=None, as_num
     if img.dtype == torch.uint8:
         _require_hip(img, "img")
         img_u8 = img.contiguous()
-        hist_img = torch.bincount(img_u8.reshape(-1).to(torch.int64), minlength=256)
+        hist_img = histogram_u8(img_u8)
     else:
         img_u8, hist_img = image_to_gray_u8(img)
     if tuple(img_u8.shape) != tuple(attention.shape):
