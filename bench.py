@@ -150,8 +150,12 @@ def slab_sweep(args, dev, world, rank, lib):
         mpp = 3 if args.precision == "bf16x3" else 1
         peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "fp32" else PEAK_BF16_DENSE_TFLOPS
         ach = cf[dom] / avg_s / 1e12
+        try:    # HBM-side bytes per launch of that kernel from the slab's own PMC passes (tools/pmc_traffic.py)
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["slab_" + args.precision][dom]["traffic_bytes"]
+        except (OSError, KeyError, ValueError):
+            traffic = None
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(ach / peak, 4), "traffic": None, "launches": int(cnt[i]), "avg_launch_us": round(avg_s * 1e6, 2),
+                "frac": round(ach / peak, 4), "traffic": traffic, "launches": int(cnt[i]), "avg_launch_us": round(avg_s * 1e6, 2),
                 "flop_per_launch": cf[dom], "mfma_per_product": mpp, "mfma_pipe_frac": round(ach * mpp / peak, 4),
                 "note": "per launch of 16 windows (the last launches of a rank hold 14-15)"}
     T = maps.shape[0]
