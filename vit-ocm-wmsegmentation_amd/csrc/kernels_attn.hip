@@ -30,6 +30,7 @@
 
 #define LOG2E 1.4426950408889634f
 int ocm_wt_mask();  // kernels_gemm.hip
+#define OCM_VMCNT_ATTN(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 template <bool WANT_O>
 // compiled for three waves per SIMD (<= 168 registers, no spills): the softmax VALU work of one wave overlaps the
@@ -618,7 +619,9 @@ __global__ __launch_bounds__(256) void attn_probs_f32_kernel(const float *__rest
 // 64 keys is two images (one per 128-byte group) of [64 rows][128 B] with the usual chunk swizzle, so the
 // fragment reads are the conflict-free pattern of the bf16 kernel and staging is a byte copy.
 // NW waves (4 or 8) of 32 queries share the K / V^T tiles: 8 waves halve the L2 -> LDS bytes per query at the same
-// waves per CU (one 8-wave workgroup instead of two 4-wave ones; N = 2305: 440 -> measured below us per launch).
+// waves per CU (one 8-wave workgroup instead of two 4-wave ones).
+// Register-staged form: kept behind knob 6 = 1 for A/B runs; attn_fwd_x3_dma_kernel below is the one dispatched
+// (ViT-S/16 B = 64: 35.0 -> 28.4 us per launch; N = 2305: 463 -> 371 us, same box, alternating runs).
 template <bool WANT_O, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_x3_kernel(const char *__restrict__ Q, const char *__restrict__ Kk,
                                                              const char *__restrict__ Vt, char *__restrict__ ctx,
@@ -694,14 +697,24 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_x3_kernel(const char *__r
     lds_barrier();
     for (int kt = 0; kt < ntiles; ++kt) {
         const int buf = kt & 1;
+#if !defined(OCM_ABL) || OCM_ABL != 5  // ablation 5: tile 0 reused, no staging after the prologue
         if (kt + 1 < ntiles) issue(kt + 1);
+#endif
+#if defined(OCM_ABL) && OCM_ABL == 6  // ablation 6: staging only, no arithmetic
+        if (false) {
+#else
         if (active) {
+#endif
             const char *Kt = Ks + buf * 16384, *Vtile = Vs + buf * 16384;
+            // the second 32 keys of the tile are all padding in the last tile of N = 197 / 2305 (5 and 1 valid keys):
+            // skipping them leaves every result bit for bit (their p is exp2(-inf) = 0 and their V^T columns are 0)
+            const bool two = kt * 64 + 32 < N;  // wave-uniform
             f32x16 S[2];
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) S[sub][e] = 0.f;
+                for (int e = 0; e < 16; ++e) S[sub][e] = (sub == 1 && !two) ? -INFINITY : 0.f;
+                if (sub == 1 && !two) continue;
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const char *kp = Kt + (s >> 1) * 8192 + sub * 32 * 128;
@@ -726,13 +739,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_x3_kernel(const char *__r
             m = mn;
             float ps = 0.f;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+            for (int sub = 0; sub < 2; ++sub) {
+                if (sub == 1 && !two) continue;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const float p = fast_exp2(fmaf(S[sub][e], scale2, -mn));
                     S[sub][e] = p;
                     ps += p;
                 }
+            }
             l = fmaf(l, alpha, ps);
             if (WANT_O) {
                 if (__any(alpha != 1.0f)) {  // the running max moved somewhere in this wave
@@ -743,7 +758,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_x3_kernel(const char *__r
                     }
                 }
 #pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
+                for (int sub = 0; sub < 2; ++sub) {
+                    if (sub == 1 && !two) continue;
 #pragma unroll
                     for (int s2 = 0; s2 < 2; ++s2) {
                         bf16x8 ph, pl;
@@ -762,11 +778,239 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_x3_kernel(const char *__r
                             O[db] = mfma32x3(vh, vl, ph, pl, O[db]);
                         }
                     }
+                }
             }
         }
+#if !defined(OCM_ABL) || OCM_ABL != 5
         if (kt + 1 < ntiles) commit(buf ^ 1);
+#endif
         lds_barrier();
     }
+
+    if (!active) return;
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const int qrow = q0 + r;
+    if (qrow < N) {
+        if (lse2 && h == 0) lse2[(int64_t)bh * N + qrow] = m + __log2f(lt);
+        if (WANT_O) {
+            const float inv = 1.0f / lt;
+            const int b = bh / H, head = bh - b * H;
+            char *dst = ctx + ((int64_t)b * N + qrow) * (H * 64) * 4 + head * 256;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = O[db][4 * g + e] * inv;
+                    bf16x4 oh, ol;
+                    split4(o, oh, ol);
+                    char *p = dst + db * 128 + (8 * g + 4 * h) * 2;
+                    if (wt) {  // write-through: the context rows are consumed by another kernel, not by this one
+                        const f32x2 dh = __builtin_bit_cast(f32x2, oh), dl = __builtin_bit_cast(f32x2, ol);
+                        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(dh) : "memory");
+                        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(p + 64), "v"(dl) : "memory");
+                    } else {
+                        *(bf16x4 *)p = oh;
+                        *(bf16x4 *)(p + 64) = ol;
+                    }
+                }
+        }
+    }
+}
+
+
+// LDS-DMA form of attn_fwd_x3_kernel (the dispatched one). Same arithmetic per key, but
+//   * K / V^T tiles of 32 keys go global -> LDS by `buffer_load ... lds` (1 KiB = 8 LDS rows per wave instruction, the
+//     chunk swizzle applied to the per-lane SOURCE offset, the tile index in the scalar offset): no staging registers,
+//     no ds_write, no per-tile address arithmetic (the register-staged kernel spent as many vector instructions on
+//     staging as on the softmax);
+//   * a ring of three 16 KiB stages (K: two [32 keys][128 B] images, V^T: one [64 d][128 B] image), two tiles in
+//     flight, one counted `s_waitcnt vmcnt` + one barrier per tile;
+//   * 48 KiB of LDS and <= 168 registers: three 4-wave workgroups per CU, so the 768 workgroups of ViT-S/16 at B = 64
+//     are resident at once (the 64 KiB / 198-register kernel ran them in one and a half rounds of two).
+// Padding keys of the last tile: their K rows are inside the buffer (scores overwritten with -inf), their V^T columns
+// are zeroed in LDS after the tile has landed (the qkv epilogue never writes them; 0 * garbage must not be NaN).
+template <bool WANT_O, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const char *__restrict__ Q,
+                                                                       const char *__restrict__ Kk,
+                                                                       const char *__restrict__ Vt, char *__restrict__ ctx,
+                                                                       float *__restrict__ lse2, int N, int npad, int H,
+                                                                       float scale2, int wt) {
+    constexpr int NSTAGE = 3, STAGE = 16384, KP = 8 / NW, VP = WANT_O ? 8 / NW : 0, LPS = KP + VP;
+    static_assert(NW == 4 || NW == 8, "8 pieces of 1 KiB per operand and tile");
+    __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int qblk, bh;
+    xcd_remap2(qblk, bh);
+    const int q0 = (qblk * NW + wave) * 32;
+    const bool active = q0 < N;  // wave-uniform
+    const char *Qb = Q + (int64_t)bh * npad * 256;
+    const char *Kb = Kk + (int64_t)bh * npad * 256;
+    const char *Vb = Vt + (int64_t)bh * 64 * npad * 4;
+    const int ntiles = (N + 31) >> 5;
+
+    // Q^T as the B operand: issued first, so the counted waits below cover it too (vmcnt retires in order)
+    bf16x8 qh[4], ql[4];
+    {
+        const char *qp = Qb + (int64_t)min(q0 + r, N - 1) * 256;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const char *p = qp + (s >> 1) * 128 + ((s & 1) * 16 + 8 * h) * 2;
+            qh[s] = *(const bf16x8 *)p;
+            ql[s] = *(const bf16x8 *)(p + 64);
+        }
+    }
+
+    // piece pc = j * NW + wave of a stage: K pieces 0..7 = image (pc >> 2), rows (pc & 3) * 8 .. + 7; V^T pieces = d rows
+    int voffK[KP], voffV[VP ? VP : 1];
+    {
+        const int lrow = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const int pc = j * NW + wave, rho = (pc & 3) * 8 + lrow;
+            voffK[j] = rho * 256 + (pc >> 2) * 128 + ((slot ^ ((rho >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < VP; ++j) {
+            const int rho = (j * NW + wave) * 8 + lrow;
+            voffV[j] = rho * npad * 4 + ((slot ^ ((rho >> 1) & 7)) << 4);
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, (unsigned)(npad * 256), 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, (unsigned)(64 * npad * 4), 0x00020000);
+#define OCM_ATTN_DMA(t, st)                                                                                              \
+    do {                                                                                                                 \
+        char *st_ = smem + (st) * STAGE;                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < KP; ++j)                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(st_ + (j * NW + wave) * 1024), 16, voffK[j],       \
+                                                     (t) * 8192, 0, 0);                                                  \
+        _Pragma("unroll") for (int j = 0; j < VP; ++j)                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(st_ + 8192 + (j * NW + wave) * 1024), 16, voffV[j], \
+                                                     (t) * 128, 0, 0);                                                   \
+    } while (0)
+#else
+#define OCM_ATTN_DMA(t, st) (void)0
+#endif
+
+    OCM_ATTN_DMA(0, 0);
+    if (ntiles > 1) OCM_ATTN_DMA(1, 1);
+    // Q and the first two tiles have landed before the loop (builtin, not asm: hipcc's own wait-count bookkeeping must
+    // see that the Q registers are complete, or it re-waits for them inside the loop with a count that also covers the
+    // tile in flight). 0x0F70 = vmcnt(0), expcnt / lgkmcnt untouched.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    f32x16 O[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[0][e] = O[1][e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int pr = pi_row(r);
+    const int first_pad = N - (ntiles - 1) * 32;  // valid keys of the last tile (1..32)
+    int sc = 0, si = 2;                           // stage computed next / filled next
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        // own DMAs of tile kt have landed once at most the younger tile kt+1 is pending
+        if (kt + 1 < ntiles)
+            OCM_VMCNT_ATTN(LPS);
+        else
+            OCM_VMCNT_ATTN(0);
+        // own LDS reads of tile kt-1 retired, then the barrier. Hand-written: a workgroup release fence on LDS makes hipcc
+        // wait for vmcnt(0) as well (LDS-DMA writes LDS), which would serialise the tile in flight behind this one
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#if !defined(OCM_ABL) || OCM_ABL != 5  // ablation 5: no staging after the prologue
+        if (kt + 2 < ntiles) OCM_ATTN_DMA(kt + 2, si);  // into the stage of tile kt-1: everybody is past it
+#endif
+        char *Kt = smem + sc * STAGE, *Vtile = Kt + 8192;
+        if (WANT_O && kt + 1 == ntiles && first_pad < 32) {  // zero the V^T columns of the padding keys (wave-uniform)
+            if (tid < 256) {
+                const int d = tid >> 2, kc = tid & 3;
+                if (kc * 8 + 8 > first_pad) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        bf16x8 *p = (bf16x8 *)(Vtile + lds_off(d, half * 4 + kc));
+                        bf16x8 t = *p;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (kc * 8 + e >= first_pad) t[e] = (bf16)0.f;
+                        *p = t;
+                    }
+                }
+            }
+            lds_barrier();
+        }
+#if defined(OCM_ABL) && OCM_ABL == 6  // ablation 6: staging only, no arithmetic
+        if (false) {
+#else
+        if (active) {
+#endif
+            f32x16 S;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const char *kp = Kt + (s >> 1) * 4096;
+                const bf16x8 kh = *(const bf16x8 *)(kp + lds_off(pr, (s & 1) * 2 + h));
+                const bf16x8 kl = *(const bf16x8 *)(kp + lds_off(pr, 4 + (s & 1) * 2 + h));
+                S = mfma32x3(kh, kl, qh[s], ql[s], S);
+            }
+            if (kt + 1 == ntiles && first_pad < 32) {  // padding keys -> -inf (wave-uniform branch)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    if (key_of_reg(e, h) >= first_pad) S[e] = -INFINITY;
+            }
+            float mx = S[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, S[e]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx * scale2);  // finite: every tile holds at least one valid key
+            const float alpha = fast_exp2(m - mn);
+            m = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = fast_exp2(fmaf(S[e], scale2, -mn));
+                S[e] = p;
+                ps += p;
+            }
+            l = fmaf(l, alpha, ps);
+            if (WANT_O) {
+                if (__any(alpha != 1.0f)) {  // the running max moved somewhere in this wave
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        O[0][e] *= alpha;
+                        O[1][e] *= alpha;
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 ph, pl;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float pv = S[8 * s2 + e];
+                        const bf16 t = (bf16)pv;
+                        ph[e] = t;
+                        pl[e] = (bf16)(pv - (float)t);
+                    }
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        const char *vp = Vtile + db * 32 * 128;
+                        const bf16x8 vh = *(const bf16x8 *)(vp + lds_off(r, 2 * s2 + h));
+                        const bf16x8 vl = *(const bf16x8 *)(vp + lds_off(r, 4 + 2 * s2 + h));
+                        O[db] = mfma32x3(vh, vl, ph, pl, O[db]);
+                    }
+                }
+            }
+        }
+        sc = sc == NSTAGE - 1 ? 0 : sc + 1;
+        si = si == NSTAGE - 1 ? 0 : si + 1;
+    }
+#undef OCM_ATTN_DMA
 
     if (!active) return;
     const float lt = l + __shfl_xor(l, 32, 64);
@@ -1183,11 +1427,22 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
 #define OCM_X3_ATTN(WO, NW_, G, B_)                                                                                      \
     attn_fwd_x3_kernel<WO, NW_><<<G, B_, 0, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx, lse2, \
                                                  n_tokens, n_pad, heads, scale * LOG2E, (ocm_wt_mask() >> 4) & 1)
-        if (wide) {
-            if (ctx) OCM_X3_ATTN(true, 8, grid8, block8); else OCM_X3_ATTN(false, 8, grid8, block8);
+#define OCM_X3_ATTN_DMA(WO, NW_, WPS_, G, B_)                                                                          \
+    attn_fwd_x3_dma_kernel<WO, NW_, WPS_><<<G, B_, 0, s>>>((const char *)q, (const char *)k, (const char *)vt,          \
+                                                           (char *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E,    \
+                                                           (ocm_wt_mask() >> 4) & 1)
+        if (g_ocm_knobs[6] == 1) {  // the register-staged streaming kernel (A/B runs)
+            if (wide) {
+                if (ctx) OCM_X3_ATTN(true, 8, grid8, block8); else OCM_X3_ATTN(false, 8, grid8, block8);
+            } else {
+                if (ctx) OCM_X3_ATTN(true, 4, grid, block); else OCM_X3_ATTN(false, 4, grid, block);
+            }
+        } else if (wide) {
+            if (ctx) OCM_X3_ATTN_DMA(true, 8, 2, grid8, block8); else OCM_X3_ATTN_DMA(false, 8, 2, grid8, block8);
         } else {
-            if (ctx) OCM_X3_ATTN(true, 4, grid, block); else OCM_X3_ATTN(false, 4, grid, block);
+            if (ctx) OCM_X3_ATTN_DMA(true, 4, 3, grid, block); else OCM_X3_ATTN_DMA(false, 4, 3, grid, block);
         }
+#undef OCM_X3_ATTN_DMA
 #undef OCM_X3_ATTN
         return hipGetLastError();
     }

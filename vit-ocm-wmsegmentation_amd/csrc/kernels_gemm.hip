@@ -34,8 +34,9 @@ static hipError_t ensure_lds_optin(const void *kern, int bytes, unsigned long lo
 }
 
 // development knobs (ocm_debug_knob; 0 = shipped behaviour): [0] nn.Linear GEMM variant, [3] qkv GEMM variant,
-// [4] = 2 fused GEMM+LayerNorm on the LDS-DMA loop, [5] LayerNorm fusion 1 = never / 2 = always, [6] = 2 whole-sequence
-// split-bf16 attention. (A start-up stagger of co-resident workgroups was tried through knobs 1 / 2 and removed:
+// [4] = 2 fused GEMM+LayerNorm on the LDS-DMA loop, [5] LayerNorm fusion 1 = never / 2 = always, [6] split-bf16
+// attention 1 = register-staged streaming kernel / 2 = whole-sequence kernel (shipped: LDS-DMA streaming kernel), [7] its
+// 8-wave form 1 = never / 2 = always. (A start-up stagger of co-resident workgroups was tried through knobs 1 / 2 and removed:
 // no gain at any delay)
 int g_ocm_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 // Write-through (sc1) stores of streaming activation outputs, as a bit mask: 1 = nn.Linear activation outputs (fc1's
