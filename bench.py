@@ -114,7 +114,7 @@ def slab_sweep(args, dev, world, rank, lib):
     model.load_state_dict(synth.synth_arch_state_dict("vit_small", 8, seed=0, variant="init"))
     model.eval().to(dev).set_precision(args.precision)
     slab = synth.synth_tiles(1, args.slab_size, seed=7)[0].to(dev)
-    sweep = SlidingWindowAttention(model, window=384, stride=128, batch_tiles=16)
+    sweep = SlidingWindowAttention(model, window=384, stride=128, batch_tiles="auto")
 
     def sync():
         torch.cuda.synchronize()
@@ -142,8 +142,12 @@ def slab_sweep(args, dev, world, rank, lib):
     torch.cuda.synchronize()
     _lib.check(lib.ocm_prof_end(ms, cnt))
     if rank == 0:
-        D, Hh, N, B = 384, 6, 2305, 16
-        cf = class_flops(D, 4 * D, N, B, 8, 3)
+        D, Hh, N = 384, 6, 2305
+        from vit_ocm_wmsegmentation_amd.sw_processing import shard_range
+        b0, e0, _ = shard_range(maps.shape[0], world, rank)
+        plan = sweep._plan(e0 - b0, N, dev)  # windows per forward on this rank (auto: whole rounds of the CUs)
+        cf1 = class_flops(D, 4 * D, N, 1, 8, 3)
+        cf = {c: v * (e0 - b0) / len(plan) for c, v in cf1.items()}  # mean FLOPs per launch
         dom = max((c for c in _lib.KERNEL_CLASSES if c in cf), key=lambda c: ms[_lib.KERNEL_CLASSES.index(c)])
         i = _lib.KERNEL_CLASSES.index(dom)
         avg_s = ms[i] / max(cnt[i], 1) * 1e-3
@@ -157,12 +161,12 @@ def slab_sweep(args, dev, world, rank, lib):
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(ach / peak, 4), "traffic": traffic, "launches": int(cnt[i]), "avg_launch_us": round(avg_s * 1e6, 2),
                 "flop_per_launch": cf[dom], "mfma_per_product": mpp, "mfma_pipe_frac": round(ach * mpp / peak, 4),
-                "note": "per launch of 16 windows (the last launches of a rank hold 14-15)"}
+                "note": f"per launch of {min(plan)}-{max(plan)} windows ({len(plan)} forwards per sweep on this rank)"}
     T = maps.shape[0]
     fwin, _ = flops_per_tile(384, 12, 8, 384)
     if rank != 0:
         return None
-    return {"workload": f"vit_small patch 8, {args.slab_size}^2 slab -> {T} windows of 384^2 (N=2305), 16 windows per forward, "
+    return {"workload": f"vit_small patch 8, {args.slab_size}^2 slab -> {T} windows of 384^2 (N=2305), up to 24 windows per forward (auto), "
                         f"CLS-row maps, tile shard x{world} + one all-gather", "scaling": "strong", "n_gpus": world,
             "windows": T, "ms_per_sweep": round(dt * 1e3, 2), "value": round(T / dt, 1), "unit": "windows/s",
             "path_tflops": round(T / dt * fwin / 1e12, 2), "roofline": roof}

@@ -137,6 +137,22 @@ def test_batch_plan_is_balanced():
         assert len(p) == -(-count // bt)
 
 
+def test_auto_batch_plan_fills_whole_rounds_of_row_tiles():
+    auto = sw.SlidingWindowAttention.auto_batch_plan
+    rounds = lambda plan, n, cus: sum(-(-(-(-b * n // 64)) // cus) for b in plan)
+    p = auto(900, 2305, 256)  # the slab sweep on one GPU: 21 windows = 757 row tiles = 2.96 rounds of 256 CUs
+    assert sum(p) == 900 and max(p) == 21 and min(p) == 20 and len(p) == 43
+    p8 = auto(113, 2305, 256)  # a rank's share on 8 GPUs
+    assert sum(p8) == 113 and max(p8) - min(p8) <= 1 and max(p8) <= 24
+    assert rounds(p8, 2305, 256) <= rounds(sw.SlidingWindowAttention.batch_plan(113, 16), 2305, 256)
+    assert auto(30, 197, 256) == [15, 15]   # short sequences: one round whatever the size -> the fewest forwards
+    assert auto(5, 2305, 256, max_batch=24) == [5] and auto(0, 2305, 256) == []
+    for count in (1, 7, 24, 25, 113, 450, 900):
+        for n in (197, 785, 2305):
+            p = auto(count, n, 256)
+            assert sum(p) == count and all(0 < x <= 24 for x in p) and max(p) - min(p) <= 1
+
+
 def test_gather_is_identity_without_process_group():
     local = torch.arange(12.).reshape(4, 3)
     assert torch.equal(sw.gather_tile_maps(local, 3), local[:3])

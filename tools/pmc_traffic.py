@@ -16,12 +16,12 @@ CLASSES = {
         "fc2_gemm": "gemm_kernel<GemmCfg<64, 384, 2, 4>, sp32, false, 48,",
         "proj_gemm": "gemm_kernel<GemmCfg<64, 384, 2, 4>, sp32, false, 12,",
         "qkv_gemm": "qkv_kernel<GemmCfg<128, 128, 2, 4>, sp32,",
-        "attention": "attn_fwd_x3_kernel<true,",
+        "attention": "attn_fwd_x3_dma_kernel<true, 4, 3>",
         "patch_embed": "gemm_kernel<GemmCfg<64, 128, 2, 2>, sp32, false, 24, PatchLoader<",
     },
-    # config 4 (ViT-S/8 slab sweep, 16 windows of 2305 tokens per launch): summaries of tools/sweep_slab.py runs
+    # config 4 (ViT-S/8 slab sweep, 20-21 windows of 2305 tokens per launch): summaries of tools/sweep_slab.py runs
     "slab_bf16x3": {
-        "attention": "attn_fwd_x3_kernel<true, 8>",
+        "attention": "attn_fwd_x3_dma_kernel<true, 8, 2>",
         "fc2_gemm": "gemm_kernel<GemmCfg<64, 384, 2, 4>, sp32, false, 48,",
         "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 12,",
     },
@@ -32,8 +32,9 @@ D, HID = 384, 1536
 
 def algorithmic_bytes(prec):
     e = 4 if prec.endswith("bf16x3") else 2                 # operand bytes per element
-    # tokens per launch: the bench workload (ViT-S/16, 224^2, 64 tiles of 197) or 16 slab windows of 2305
-    T = 16 * 2305 if prec.startswith("slab") else 64 * 197
+    # tokens per launch: the bench workload (ViT-S/16, 224^2, 64 tiles of 197) or the slab sweep's mean launch
+    # (900 windows of 2305 tokens in 43 forwards of 20-21: SlidingWindowAttention.auto_batch_plan)
+    T = round(900 / 43 * 2305) if prec.startswith("slab") else 64 * 197
     qkv_out = 3 * T * D * e                                 # q, k, v^T: valid tokens only (pad rows are never written)
     return {
         "fc1_gemm": T * D * e + D * HID * e + T * HID * e,

@@ -2,7 +2,7 @@
 """Sliding-window sweep of a synthetic slab (BASELINE.json configs[3]: ViT-S/8, 384-px windows at stride 128)
 through SlidingWindowAttention on the local rank(s). Prints windows/s. GPU box only.
 
-    python tools/sweep_slab.py [--size 4096] [--batch 16] [--arch vit_small] [--patch 8]
+    python tools/sweep_slab.py [--size 4096] [--batch auto|16] [--arch vit_small] [--patch 8]
     python -m torch.distributed.run --nproc-per-node N ... tools/sweep_slab.py   (tile shard + all-gather)
 """
 import argparse
@@ -20,7 +20,7 @@ from vit_ocm_wmsegmentation_amd.sw_processing import SlidingWindowAttention
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=4096)
-ap.add_argument("--batch", type=int, default=16)
+ap.add_argument("--batch", default="auto", help="windows per forward, or auto (SlidingWindowAttention.auto_batch_plan)")
 ap.add_argument("--arch", default="vit_small")
 ap.add_argument("--patch", type=int, default=8)
 ap.add_argument("--reps", type=int, default=2)
@@ -35,7 +35,7 @@ model = vits.__dict__[a.arch](patch_size=a.patch, num_classes=0)
 model.load_state_dict(synth.synth_arch_state_dict(a.arch, a.patch, variant="init"))
 model.eval().to(dev)
 slab = synth.synth_tiles(1, a.size, seed=7)[0].to(dev)
-sweep = SlidingWindowAttention(model, window=384, stride=128, batch_tiles=a.batch)
+sweep = SlidingWindowAttention(model, window=384, stride=128, batch_tiles=a.batch if a.batch == "auto" else int(a.batch))
 maps = sweep(slab)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
