@@ -658,14 +658,23 @@ static hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, 
     const long t128 = (long)((M + 127) / 128) * (3 * D / 128);
     if constexpr (Elem<E>::MODE == 2) {
         if (D % 128 == 0 && M > 64) {
-            switch (g_ocm_knobs[3]) {  // development: 1 / 2 / 3 force an LDS-DMA variant (same speed in the forward)
+            switch (g_ocm_knobs[3]) {  // development: force a variant (-1: the register-staged kernels below)
                 case 1: return launch_qkv_dma<Cfg128x128, E, 2>(a, w, M, D, eqk, ev, s);
                 case 2: return launch_qkv_dma<Cfg128x128q, E, 2>(a, w, M, D, eqk, ev, s);
                 case 3: return launch_qkv_dma<Cfg64x128, E, 2>(a, w, M, D, eqk, ev, s);
+                case 4: if (D % 256 == 0) return launch_qkv_dma<Cfg256x256, E, 2>(a, w, M, D, eqk, ev, s); break;
                 default: break;
             }
-            // few rows (one tile per call): the DMA loop's shorter prologue shows (B = 1 forward 1.03 -> 1.01 ms)
-            if (M <= 1024 && g_ocm_knobs[3] == 0) return launch_qkv_dma<Cfg64x128, E, 2>(a, w, M, D, eqk, ev, s);
+            if (g_ocm_knobs[3] == 0) {
+                // few rows (one tile per call): the DMA loop's shorter prologue shows (B = 1 forward 1.03 -> 1.01 ms)
+                if (M <= 1024) return launch_qkv_dma<Cfg64x128, E, 2>(a, w, M, D, eqk, ev, s);
+                // ViT-B sizes: 256 x 256 tiles halve the bytes through L2 (384^2 B = 128: 755 -> 715 us per launch)
+                if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_dma<Cfg256x256, E, 2>(a, w, M, D, eqk, ev, s);
+                // the 8-wave 128 x 128 tile on the LDS-DMA loop (ViT-S/16 B = 64: 46.6 -> 41.8 us per launch, +2 % end
+                // to end; ViT-B/16 384^2 B = 128: 805 -> 759 us; alternating runs on one box). The 4-wave form of the
+                // same tile (variant 1) measures like the register-staged kernel.
+                if (t128 >= 512) return launch_qkv_dma<Cfg128x128q, E, 2>(a, w, M, D, eqk, ev, s);
+            }
         }
     }
     if (D % 128 == 0 && t128 >= 512) return launch_qkv_cfg<Cfg128x128q, E>(al, w, M, D, eqk, ev, s);
