@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCM_ABI_VERSION 4
+#define OCM_ABI_VERSION 5
 
 enum {
     OCM_OK = 0,
@@ -207,6 +207,16 @@ enum {
  * K % 64 == 0, N % 32 == 0. resid may alias out. */
 int ocm_op_linear(int32_t precision, const void *a, const void *w, const float *bias, const float *resid,
                   void *out, int32_t M, int32_t N, int32_t K, int32_t epilogue, void *stream);
+
+/* nn.Linear + residual + LayerNorm in one kernel (Block.forward :107-111 with the NEXT normalisation folded in:
+ *   x = resid + A[M][K] · W[D][K]^T + bias;   xn = LayerNorm(x; gamma, beta, eps) in the activation type E
+ * exactly as ocm_op_linear (epilogue RESID_F32) followed by ocm_op_layernorm would produce them (bit for bit).
+ * A workgroup owns whole rows, so D is one of 128 / 256 / 384 / 512 (ocm_linear_resid_ln_supported). resid may
+ * alias x. The engine uses it for attn.proj -> norm2 and mlp.fc2 -> the next block's norm1 when M >= 8192. */
+int ocm_linear_resid_ln_supported(int32_t D);
+int ocm_op_linear_resid_ln(int32_t precision, const void *a, const void *w, const float *bias, const float *resid,
+                           float *x, const float *gamma, const float *beta, void *xn, int32_t M, int32_t D, int32_t K,
+                           float eps, void *stream);
 
 /* Head-major packed projections the attention kernels consume:
  *   q, k : E [B*H][n_pad][64];  vt : E [B*H][64][n_pad],  n_pad = ocm_n_pad_prec(precision, N)

@@ -146,3 +146,39 @@ def test_attention_x3(lib, dev, B, N, H, sharp):
     rows = torch.empty((B, H, 3, N - 1), device=dev)
     _ok(lib, lib.ocm_op_attention_rows(X3, _p(qs), _p(ks), _p(rows_idx), 3, _p(rows), B, N, H, scale, _s()))
     assert (rows.double() - pref.reshape(B, H, N, N)[:, :, rows_idx.long(), 1:]).abs().max().item() < 2e-5 * es
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32", "bf16x3"])
+@pytest.mark.parametrize("M,D,K", [(1000, 384, 384), (12608, 384, 1536), (70, 128, 192), (333, 512, 512), (64, 256, 64)])
+def test_linear_resid_ln_equals_linear_then_layernorm(lib, dev, prec, M, D, K):
+    """ocm_op_linear_resid_ln (one kernel: GEMM + bias + residual, then LayerNorm of the rows it has just produced) is
+    bit for bit ocm_op_linear(RESID_F32) followed by ocm_op_layernorm, in every precision mode, and sits where the
+    float64 reference says (Block.forward, dino/vision_transformer.py:107-111)."""
+    pc = _lib.PRECISIONS[prec]
+    assert lib.ocm_linear_resid_ln_supported(D) == 1 and lib.ocm_linear_resid_ln_supported(96) == 0
+    a, w = _rand((M, K), dev, 70), _rand((D, K), dev, 71, 0.05)
+    bias, resid = _rand((D,), dev, 72, 0.1), _rand((M, D), dev, 73)
+    gamma, beta = _rand((D,), dev, 74) * 0.1 + 1, _rand((D,), dev, 75) * 0.1
+    a_s, w_s = to_operand(a, pc), to_operand(w, pc)
+    out_kind = {"bf16": _lib.OCM_LN_BF16, "fp32": _lib.OCM_LN_F32, "bf16x3": _lib.OCM_LN_SPLIT}[prec]
+    act = {"bf16": torch.bfloat16, "fp32": torch.float32, "bf16x3": torch.int32}[prec]
+    # two kernels
+    x2 = resid.clone()
+    _ok(lib, lib.ocm_op_linear(pc, _p(a_s), _p(w_s), _p(bias), _p(x2), _p(x2), M, D, K, _lib.OCM_EPI_BIAS_RESID_F32, _s()))
+    xn2 = torch.empty((M, D), dtype=act, device=dev)
+    _ok(lib, lib.ocm_op_layernorm(_p(x2), _p(gamma), _p(beta), _p(xn2), out_kind, M, D, 1e-6, _s()))
+    # one kernel (resid aliases x, as the engine calls it)
+    x1 = resid.clone()
+    xn1 = torch.empty((M, D), dtype=act, device=dev)
+    _ok(lib, lib.ocm_op_linear_resid_ln(pc, _p(a_s), _p(w_s), _p(bias), _p(x1), _p(x1), _p(gamma), _p(beta), _p(xn1),
+                                        M, D, K, 1e-6, _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x2)
+    assert torch.equal(xn1.view(torch.int32) if act != torch.bfloat16 else xn1.view(torch.int16),
+                       xn2.view(torch.int32) if act != torch.bfloat16 else xn2.view(torch.int16))
+    ref = resid.double() + a.double() @ w.double().t() + bias.double()
+    tol = {"bf16": 2e-2, "fp32": 2e-4, "bf16x3": 3e-5}[prec] * max(1.0, math.sqrt(K) / 8)
+    assert (x1.double() - ref).abs().max().item() < tol
+    with pytest.raises(AssertionError):
+        _ok(lib, lib.ocm_op_linear_resid_ln(pc, _p(a_s), _p(w_s), _p(bias), _p(x1), _p(x1), _p(gamma), _p(beta), _p(xn1),
+                                            M, 96, K, 1e-6, _s()))

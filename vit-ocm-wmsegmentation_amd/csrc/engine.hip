@@ -639,6 +639,20 @@ extern "C" int ocm_op_linear(int32_t precision, const void *a, const void *w, co
     return OCM_OK;
 }
 
+extern "C" int ocm_linear_resid_ln_supported(int32_t D) { return linear_resid_ln_supported(D) ? 1 : 0; }
+
+extern "C" int ocm_op_linear_resid_ln(int32_t precision, const void *a, const void *w, const float *bias,
+                                      const float *resid, float *x, const float *gamma, const float *beta, void *xn,
+                                      int32_t M, int32_t D, int32_t K, float eps, void *stream) {
+    int pc = 0, rc = prec_of(precision, &pc);
+    if (rc) return rc;
+    if (!a || !w || !resid || !x || !gamma || !beta || !xn) return fail(OCM_EINVAL, "null argument");
+    if (!linear_resid_ln_supported(D)) return fail(OCM_EINVAL, "row width %d not in {128, 256, 384, 512}", D);
+    if (M <= 0 || K <= 0 || K % 64) return fail(OCM_EINVAL, "bad shape M=%d K=%d (K%%64)", M, K);
+    HIP_TRY(launch_linear_resid_ln(pc, a, w, bias, resid, x, gamma, beta, xn, M, D, K, eps, (hipStream_t)stream));
+    return OCM_OK;
+}
+
 extern "C" int ocm_op_qkv_proj(int32_t precision, const void *a, const void *w, const float *bias, void *q, void *k,
                                void *vt, float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads, void *stream) {
     int pc = 0, rc = prec_of(precision, &pc);

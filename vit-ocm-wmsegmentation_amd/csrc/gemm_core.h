@@ -89,6 +89,9 @@ struct RowLoader {
     __device__ __forceinline__ Handle row(int m) const { return (const char *)A + (int64_t)m * lda * (int)sizeof(E); }
     // chunk c of K step t
     __device__ __forceinline__ Raw load(Handle h, int t, int c) const {
+#if defined(OCM_ABL) && OCM_ABL == 8  // ablation 8: the A operand re-reads its first K step (cache hits)
+        t = 0;
+#endif
         return *(const Raw *)(h + t * 128 + c * 16);
     }
     __device__ __forceinline__ static Raw finish(const Raw &r, int) { return r; }
@@ -202,7 +205,11 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) sl.a[i] = al.load(a_h[i], t, cc);
 #pragma unroll
+#if defined(OCM_ABL) && OCM_ABL == 9  // ablation 9: the W operand re-reads its first K step (cache hits)
+        for (int i = 0; i < B_CH; ++i) sl.b[i] = *(const Chunk *)(b_h[i]);
+#else
         for (int i = 0; i < B_CH; ++i) sl.b[i] = *(const Chunk *)(b_h[i] + t * 128);
+#endif
     };
     auto commit = [&](int buf, const Slot &sl) {
 #pragma unroll
@@ -247,6 +254,9 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
         commit(0, s0);
         issue2(s0, 2);
         lds_barrier();
+#ifdef OCM_GEMM_STAMPS
+        STAMP(6);  // first tile in LDS
+#endif
         if constexpr (KSTEPS % 2 == 0) {
             for (int t = 0; t < KSTEPS; t += 2) {
                 compute(0);     // step t (even steps live in buffer 0)

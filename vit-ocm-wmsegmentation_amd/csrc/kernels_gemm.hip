@@ -799,6 +799,21 @@ hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, cons
 }
 
 #ifdef OCM_GEMM_STAMPS
+// development only: workgroups per CU the runtime grants a few of the shipped kernels (tools/stamps_x3.py)
+extern "C" int ocm_debug_occupancy(int *out, int n) {
+    int k = 0, v = 0;
+    auto q = [&](const void *f, int threads, size_t lds) {
+        v = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, f, threads, lds);
+        if (k < n) out[k++] = v;
+    };
+    q((const void *)gemm_dma_kernel<Cfg64x128, sp32, false, 48, 2, EpiLinear<1, sp32>, 0>, 256, 2 * 192 * 128);
+    q((const void *)gemm_dma_kernel<Cfg128x128, sp32, false, 12, 2, EpiLinear<2, sp32>, 0>, 256, 2 * 256 * 128);
+    q((const void *)qkv_dma_kernel<Cfg128x128q, sp32, 12, 2>, 512, 2 * 256 * 128);
+    q((const void *)gemm_kernel<GemmCfg<64, 384, 2, 4>, sp32, false, 48, RowLoader<sp32>, EpiResidLN<sp32, 384>>, 512,
+      GemmCfg<64, 384, 2, 4>::LDS_BYTES);
+    return k;
+}
 // development only: copy the cycle stamps of the last GEMM launches to the host (tools/stamps.py)
 extern "C" int ocm_debug_stamps(unsigned long long *host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * 8);
