@@ -58,6 +58,11 @@ struct PassCfg {
     static constexpr int BM = PBM, BN = PBN, NT = NT_;
 };
 
+// 1: 8-wave register-staged split-bf16 main loops run their two half-workgroups in opposite phases (0: A/B builds)
+#ifndef OCM_PINGPONG
+#define OCM_PINGPONG 1
+#endif
+
 // operand element traits: an LDS row (one K step, 128 bytes) holds KROW elements; an epilogue lane writes EPW
 // consecutive elements of an activation row. MODE: 0 = bf16, 1 = fp32, 2 = split-bf16 pairs (common.h: sp32).
 // In every mode K step t of a row is the 128 bytes at byte offset t * 128 of that row, as eight 16-byte chunks.
@@ -89,7 +94,7 @@ struct RowLoader {
     __device__ __forceinline__ Handle row(int m) const { return (const char *)A + (int64_t)m * lda * (int)sizeof(E); }
     // chunk c of K step t
     __device__ __forceinline__ Raw load(Handle h, int t, int c) const {
-#if defined(OCM_ABL) && OCM_ABL == 8  // ablation 8: the A operand re-reads its first K step (cache hits)
+#if defined(OCM_ABL) && (OCM_ABL == 8 || OCM_ABL == 10)  // ablation 8 (10: both operands): the A operand re-reads its first K step (cache hits)
         t = 0;
 #endif
         return *(const Raw *)(h + t * 128 + c * 16);
@@ -103,7 +108,10 @@ __device__ __forceinline__ void mma_step(const char *Ab, const char *Bb, int r, 
                                          f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
     if constexpr (Elem<E>::MODE == 2) {
-        // split-bf16: the 128-byte row is [hi k 0..31 | lo k 0..31]; two k16 sub-steps, three MFMAs per product
+        // split-bf16: the 128-byte row is [hi k 0..31 | lo k 0..31]; two k16 sub-steps, three MFMAs per product.
+        // (hipcc interleaves these reads and MFMAs in groups of three to five reads followed by lgkmcnt(0); pinning a
+        // rolling window of reads two blocks ahead of the MFMAs with sched_group_barrier was measured on the 64 x 384
+        // tile: no gain — that kernel is paced by LDS bytes, DESIGN.md §3.8 — and the patch embedding 15 % slower.)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -205,7 +213,7 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
 #pragma unroll
         for (int i = 0; i < A_CH; ++i) sl.a[i] = al.load(a_h[i], t, cc);
 #pragma unroll
-#if defined(OCM_ABL) && OCM_ABL == 9  // ablation 9: the W operand re-reads its first K step (cache hits)
+#if defined(OCM_ABL) && (OCM_ABL == 9 || OCM_ABL == 10)  // ablation 9 (10: both operands): the W operand re-reads its first K step (cache hits)
         for (int i = 0; i < B_CH; ++i) sl.b[i] = *(const Chunk *)(b_h[i]);
 #else
         for (int i = 0; i < B_CH; ++i) sl.b[i] = *(const Chunk *)(b_h[i] + t * 128);
@@ -247,7 +255,11 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
         // in step t-2 (L2 latency under load is ~1 us, more than one step). The stream is unconditional (indices
         // past the end re-read the last tile into a dead slot) and the loop is fully unrolled with a constant
         // trip count, so hipcc counts its own `s_waitcnt vmcnt(N)` instead of draining to 0.
+#if defined(OCM_ABL) && OCM_ABL == 11  // ablation 11: no global loads after the prologue (slots keep their first tiles)
+        auto issue2 = [&](Slot &sl, int t) { if (t < 3) issue(sl, min(t, KSTEPS - 1)); };
+#else
         auto issue2 = [&](Slot &sl, int t) { issue(sl, min(t, KSTEPS - 1)); };
+#endif
         Slot s0, s1;
         issue2(s0, 0);
         issue2(s1, 1);
@@ -257,7 +269,53 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
 #ifdef OCM_GEMM_STAMPS
         STAMP(6);  // first tile in LDS
 #endif
-        if constexpr (KSTEPS % 2 == 0) {
+        if constexpr (KSTEPS % 2 == 0 && Elem<E>::MODE == 2 && NT == 512 && OCM_PINGPONG) {
+            // Eight waves = two per SIMD (waves w and w + 4 share SIMD w): run the two halves of the workgroup in
+            // OPPOSITE phases instead of in lock step. Per K step two intervals, a barrier after each:
+            //   interval 1: waves 0-3 multiply step t            | waves 4-7 commit their share of step t+1, issue t+3
+            //   interval 2: waves 0-3 commit their share of t+1  | waves 4-7 multiply step t
+            // so on every SIMD one wave's MFMAs run beside the other wave's waits, ds_writes and load issue, instead of
+            // both waves paying the LDS read latency and the wait -> ds_write -> barrier tail at the same time
+            // (stamps: 2 108 cycles per step against 1 152 of MFMA issue in lock step). Buffers: step t is read from
+            // buffer t & 1 in both intervals while shares of step t+1 land in the other buffer; a buffer is refilled
+            // only after the end-of-step barrier that follows its last reader. Same MFMA order per accumulator:
+            // bit-identical results.
+            // nothing may be scheduled across an interval boundary (hipcc otherwise sinks MFMAs below the barrier,
+            // into the partner's MFMA interval)
+            auto phase_barrier = [&]() {
+                __builtin_amdgcn_sched_barrier(0);
+                lds_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+            if (grp == 0) {
+                for (int t = 0; t < KSTEPS; t += 2) {
+                    compute(0);  // step t
+                    phase_barrier();
+                    commit(1, s1);  // own share of step t+1
+                    issue2(s1, t + 3);
+                    phase_barrier();
+                    compute(1);  // step t+1
+                    phase_barrier();
+                    commit(0, s0);  // own share of step t+2 (a dead duplicate after the last step)
+                    issue2(s0, t + 4);
+                    phase_barrier();
+                }
+            } else {
+                for (int t = 0; t < KSTEPS; t += 2) {
+                    commit(1, s1);
+                    issue2(s1, t + 3);
+                    phase_barrier();
+                    compute(0);
+                    phase_barrier();
+                    commit(0, s0);
+                    issue2(s0, t + 4);
+                    phase_barrier();
+                    compute(1);
+                    phase_barrier();
+                }
+            }
+        } else if constexpr (KSTEPS % 2 == 0) {
             for (int t = 0; t < KSTEPS; t += 2) {
                 compute(0);     // step t (even steps live in buffer 0)
                 commit(1, s1);  // step t+1
