@@ -109,7 +109,9 @@ def test_qkv_proj_x3(lib, dev, B, N, H):
     assert (from_split(vt)[:, :, N:] == 0).all()
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (1, 17, 2), (1, 577, 3), (1, 64, 1), (1, 65, 1), (1, 2305, 2)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (1, 17, 2), (1, 577, 3), (1, 64, 1), (1, 65, 1), (1, 2305, 2),
+                                   (1, 5, 1), (1, 32, 2), (1, 33, 1), (1, 1024, 1), (1, 1025, 1)])  # one tile, no padding,
+# one key into the second tile, the 4-wave / 8-wave switch
 @pytest.mark.parametrize("sharp", [1.0, 3.0])
 def test_attention_x3(lib, dev, B, N, H, sharp):
     g = torch.Generator().manual_seed(60)

@@ -15,7 +15,7 @@ CLASSES = {
         "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 12,",
         "fc2_gemm": "gemm_kernel<GemmCfg<64, 384, 2, 4>, sp32, false, 48,",
         "proj_gemm": "gemm_kernel<GemmCfg<64, 384, 2, 4>, sp32, false, 12,",
-        "qkv_gemm": "qkv_kernel<GemmCfg<128, 128, 2, 4>, sp32,",
+        "qkv_gemm": "qkv_dma_kernel<GemmCfg<128, 128, 2, 4>, sp32, 12, 2>",
         "attention": "attn_fwd_x3_dma_kernel<true, 4, 3>",
         "patch_embed": "gemm_kernel<GemmCfg<64, 128, 2, 2>, sp32, false, 24, PatchLoader<",
     },
