@@ -343,7 +343,11 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     // The fused GEMM + LayerNorm kernel owns full rows (64 x D tiles, D / 128 times the W bytes per workgroup and step):
     // it pays once there are enough row tiles to occupy the chip (measured: +2 % at T = 12 608; at T = 197, four
     // workgroups stream all of W each: 1.52 ms per forward against 1.14 ms). Knob 5: 1 = never, 2 = always.
-    const bool fuse_ln = linear_resid_ln_supported(D) && g_ocm_knobs[5] != 1 && (T >= 8192 || g_ocm_knobs[5] == 2);
+    // Above 512 tiles of 128 x 128 in the (T x D) output the un-fused pair wins again: those tiles fill two workgroups
+    // per CU and move half the LDS bytes per MFMA of a 64-row tile (ViT-S/8 slab sweep, T = 48 405: 575 -> 556 ms).
+    const long t128 = (long)((T + 127) / 128) * (D / 128);
+    const bool fuse_ln = linear_resid_ln_supported(D) && g_ocm_knobs[5] != 1 &&
+                         ((T >= 8192 && t128 < 512) || g_ocm_knobs[5] == 2);
     if (xn_out) *xn_out = false;
     // y = attn(norm1(x))
     if (!xn_ready) { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, lnk, T, D, eps, s)); }

@@ -230,29 +230,40 @@ class SlidingWindowAttention:
         return [base + (1 if i < extra else 0) for i in range(nb)]
 
     @staticmethod
-    def auto_batch_plan(count, n_tokens, cus, max_batch=24, row_tile=64):
+    def auto_batch_plan(count, n_tokens, cus, max_batch=24, dim=384):
         """Balanced batches (sizes differ by at most one, none above `max_batch`) whose count is chosen for the kernels
-        rather than fixed: the fused GEMM + LayerNorm kernels give one 64-row tile of the (batch x tokens) matrix to a
-        workgroup, one workgroup per CU, so a forward costs ceil(ceil(batch * n_tokens / 64) / CUs) rounds whether or
-        not the last round is full. The plan with the fewest rounds in total wins (ties: fewer forwards). 900 windows
-        of 2305 tokens on 256 CUs -> 43 forwards of 20-21 windows (757 tiles = 2.96 rounds each); measured on one
-        MI355X, split-bf16: 556 ms per sweep against 615 ms at 16 per forward and 599 ms at 22 (3.1 rounds -> 4)."""
+        rather than fixed. A forward is charged the rows its dominant GEMM really occupies the chip for: while the
+        (rows x dim) output holds fewer than 512 tiles of 128 x 128 (and rows >= 8192) the engine runs attn.proj /
+        mlp.fc2 fused with the following LayerNorm on 64-row tiles, one workgroup per CU — whole rounds of
+        ceil(rows / 64) tiles over the CUs; otherwise mlp.fc1's 128 x 128 tiles, two workgroups per CU — whole rounds
+        of ceil(rows / 128) * (4 dim / 128) tiles over 2 CUs slots. The plan with the lowest charge wins (ties: fewer
+        forwards). Measured on one MI355X (split-bf16, 900 windows of 2305 tokens): with every forward on the fused
+        kernels 16 / 21 / 22 windows per forward took 615 / 556 / 599 ms per sweep (2.25 / 2.96 / 3.1 rounds); with
+        the 128 x 128 tiles that large forwards now get, 16 .. 32 windows per forward all land within 522 .. 536 ms."""
         if count <= 0:
             return []
+
+        def charge(b):
+            rows = b * n_tokens
+            if dim in (128, 256, 384, 512) and rows >= 8192 and -(-rows // 128) * (dim // 128) < 512:
+                return -(-(-(-rows // 64)) // max(1, cus)) * 64 * cus
+            cols = max(1, 4 * dim // 128)
+            return -(-(-(-rows // 128) * cols) // (2 * max(1, cus))) * (2 * cus) * 128 / cols
+
         best = None
         nb_min = -(-count // max(1, max_batch))
-        for nb in range(nb_min, min(count, 2 * nb_min + 2) + 1):
+        for nb in range(nb_min, min(count, nb_min + max(2, nb_min // 2)) + 1):  # up to 1.5x the fewest forwards
             base, extra = divmod(count, nb)
             plan = [base + (1 if i < extra else 0) for i in range(nb)]
-            rounds = sum(-(-(-(-b * n_tokens // row_tile)) // max(1, cus)) for b in plan)
-            if best is None or (rounds, nb) < best[0]:
-                best = ((rounds, nb), plan)
+            cost = sum(charge(b) + 1500 for b in plan)  # + launch overhead of a forward, in rows (~0.3 ms)
+            if best is None or (cost, nb) < best[0]:
+                best = ((cost, nb), plan)
         return best[1]
 
     def _plan(self, count, n_tokens, device):
         if self.batch_tiles == "auto":
             cus = torch.cuda.get_device_properties(device).multi_processor_count if device.type == "cuda" else 256
-            return self.auto_batch_plan(count, n_tokens, cus, self.max_batch)
+            return self.auto_batch_plan(count, n_tokens, cus, self.max_batch, self._geometry(device)[2].shape[1])
         return self.batch_plan(count, self.batch_tiles)
 
     @torch.no_grad()
