@@ -17,6 +17,7 @@ import torch
 
 from oracle import vit_oracle as O
 from tests.helpers import CASES, build_module, case_dims, case_inputs, case_state_dict, load_golden
+import vit_ocm_wmsegmentation_amd.dino.vision_transformer as vits
 from vit_ocm_wmsegmentation_amd import synth
 from vit_ocm_wmsegmentation_amd import utils as amd_utils
 from vit_ocm_wmsegmentation_amd.sw_processing import SlidingWindowAttention
@@ -320,3 +321,32 @@ def test_hip_graph_replay_matches_plain_launches(dev):
     eng2.hip_graph = False
     assert torch.equal(model.get_last_selfattention(x1), changed)
     assert not torch.equal(changed, want1)
+
+
+@pytest.mark.parametrize("method,kwargs", [("get_last_selfattention", {}), ("get_intermediate_feat", {"n": 2}),
+                                           ("get_last_attention_rows", {}), ("forward", {})])
+def test_graphed_call_replays_the_same_kernels(dev, method, kwargs):
+    """model.graphed(method): HIP-graph replay of a one-tile call (what the reference's loops issue) returns bit for
+    bit what the plain call returns, follows new inputs, and re-captures on a precision or shape change."""
+    def same(a, b):
+        if isinstance(a, torch.Tensor):
+            return torch.equal(a, b)
+        return len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+
+    model = vits.vit_small(patch_size=16, num_classes=0)
+    model.load_state_dict(synth.synth_arch_state_dict("vit_small", 16, seed=3, variant="sharp"))
+    model = model.eval().to(dev)
+    run = model.graphed(method, **kwargs)
+    x1, x2 = synth.synth_tiles(1, 224, seed=11).to(dev), synth.synth_tiles(1, 224, seed=12).to(dev)
+    for x in (x1, x2, x1):
+        assert same(run(x), getattr(model, method)(x, **kwargs))
+    first = run(x1)
+    run(x2)  # copies are returned: an earlier result does not change under a later call
+    assert same(first, getattr(model, method)(x1, **kwargs))
+    model.set_precision("bf16")
+    assert same(run(x2), getattr(model, method)(x2, **kwargs))
+    model.set_precision("bf16x3")
+    x3 = synth.synth_tiles(2, 96, seed=13).to(dev)  # another batch and tile size: re-captured
+    assert same(run(x3), getattr(model, method)(x3, **kwargs))
+    with pytest.raises(AttributeError):
+        model.graphed("no_such_method")

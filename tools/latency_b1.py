@@ -36,4 +36,15 @@ for arch, p, S in (("vit_small", 16, 224), ("vit_small", 8, 384)):
             fn()
         torch.cuda.synchronize()
         dq = (time.perf_counter() - t1) / n
-        print(f"[{PREC}] {arch}/{p} {S}^2 B=1 {name:24s}: {dt * 1e3:7.3f} ms per call (synced), {dq * 1e3:7.3f} ms queued back-to-back", flush=True)
+        line = f"[{PREC}] {arch}/{p} {S}^2 B=1 {name:24s}: {dt * 1e3:7.3f} ms per call (synced), {dq * 1e3:7.3f} ms queued back-to-back"
+        if name != "get_intermediate_feat":
+            run = model.graphed(name)  # HIP-graph replay of the same call
+            for _ in range(3):
+                run(x)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(n):
+                run(x)
+                torch.cuda.synchronize()
+            line += f", {(time.perf_counter() - t2) / n * 1e3:7.3f} ms as a graph replay (synced)"
+        print(line, flush=True)

@@ -405,11 +405,85 @@ class VisionTransformer(nn.Module):
         n = max(1, min(int(n), len(self.blocks)))
         return list(self._run(x, flags=_lib.OCM_OUT_FEAT, n_last=n)["feat"].unbind(0))
 
-    # ---- MI355X-native extension used by the sliding-window driver -------------------------------
+    # ---- MI355X-native extensions ----------------------------------------------------------------
+    def graphed(self, method="get_last_selfattention", **kwargs):
+        """`method` as a HIP-graph replay for repeated same-shaped calls (one tile per call: -16 % latency):
+        `run = model.graphed("get_last_selfattention"); attn = run(img)`. See GraphedCall."""
+        return GraphedCall(self, method, kwargs)
+
     def get_last_attention_rows(self, x, query_rows=None):
         """attentions[0][:, :, query, 1:] of the last block for the given token indices (default: CLS)
         without materialising the (B,H,N,N) matrix: (B, H, n_rows, N-1) fp32."""
         return self._run(x, flags=_lib.OCM_OUT_ROWS | _lib.OCM_LAST_ATTN_ONLY, query_rows=query_rows)["rows"]
+
+
+def _tree_map(fn, obj):
+    if isinstance(obj, torch.Tensor):
+        return fn(obj)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_tree_map(fn, o) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _tree_map(fn, v) for k, v in obj.items()}
+    return obj
+
+
+class GraphedCall:
+    """One method of a VisionTransformer replayed as a HIP graph (`model.graphed("get_last_selfattention")`).
+
+    The reference's callers run one tile per call (eval.py:126-171, sw_processing.py:235-258, analyse_attention.py):
+    61 kernel launches of 5-25 us each, so a call is bound by launch overhead and inter-kernel gaps rather than by the
+    kernels. The first call with a given input shape warms the engine up, captures the method's launches on the current
+    stream into a graph whose input and outputs are fixed buffers, and every later call copies the tile in, replays
+    the graph with ONE launch and returns copies of the outputs (`clone=False`: the fixed buffers themselves, valid
+    until the next call). ViT-S/16, 224^2, B = 1, split-bf16: 0.99 -> 0.83 ms per synchronised call; results are bit
+    for bit those of the plain call (same kernels, same order). A new shape, device or precision re-captures, and so
+    does a parameter update once a plain call (or `reset()`) has seen it. Keyword arguments are captured by value / by tensor identity and must not change between calls."""
+
+    def __init__(self, model, method, kwargs):
+        if not callable(getattr(model, method, None)):
+            raise AttributeError(f"{type(model).__name__} has no method {method!r}")
+        self.model, self.method, self.kwargs = model, method, dict(kwargs)
+        self._cap = None
+
+    def _key(self, x):
+        # cheap on purpose (this runs on every call): the engine entry is replaced whenever a plain call finds changed
+        # parameters, so its identity stands for the weights; reset() forces a re-capture after an in-place update
+        m = self.model
+        return (tuple(x.shape), x.dtype, x.device, id(m._engines.get(x.device)), m._precision, m._gray_fold,
+                m.pos_embed.data_ptr(), m.pos_embed._version)
+
+    def reset(self):
+        """Drop the capture (the next call re-captures): call after updating parameters in place."""
+        self._cap = None
+
+    def _capture(self, x, key):
+        m, fn = self.model, getattr(self.model, self.method)
+        xs = x.detach().clone()
+        cur = torch.cuda.current_stream(x.device)
+        side = torch.cuda.Stream(device=x.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # warm-up off the capturing stream: engine build, workspace, LDS opt-ins
+            for _ in range(2):
+                fn(xs, **self.kwargs)
+        cur.wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = fn(xs, **self.kwargs)
+        eng = m._engine(x.device)
+        # everything the captured launches point at stays alive with the capture, whatever the engine caches next
+        keep = (eng, list(eng._ws.values()), dict(m._pos_cache))
+        self._cap = (self._key(x), graph, xs, out, keep)  # the warm-up may have (re)built the engine entry
+
+    @torch.no_grad()
+    def __call__(self, x, clone=True):
+        _require_hip(x, "input")
+        key = self._key(x)
+        if self._cap is None or self._cap[0] != key:
+            self._capture(x, key)
+        _, graph, xs, out, _ = self._cap
+        xs.copy_(x)
+        graph.replay()
+        return _tree_map(torch.clone, out) if clone else out
 
 
 def vit_tiny(patch_size=16, **kwargs):
