@@ -22,7 +22,7 @@ CLASSES = {
     # config 4 (ViT-S/8 slab sweep, 20-21 windows of 2305 tokens per launch): summaries of tools/sweep_slab.py runs
     "slab_bf16x3": {
         "attention": "attn_fwd_x3_dma_kernel<true, 8, 2>",
-        "fc2_gemm": "gemm_kernel<GemmCfg<64, 384, 2, 4>, sp32, false, 48,",
+        "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 48, 2, EpiLinear<1,",  # un-fused at this size
         "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 12,",
     },
 }
@@ -38,7 +38,8 @@ def algorithmic_bytes(prec):
     qkv_out = 3 * T * D * e                                 # q, k, v^T: valid tokens only (pad rows are never written)
     return {
         "fc1_gemm": T * D * e + D * HID * e + T * HID * e,
-        "fc2_gemm": T * HID * e + HID * D * e + T * D * 4 * 2 + T * D * e,      # + residual in/out (fp32) + xn out
+        # + residual in / out (fp32); the bench workload's fused kernel also writes xn
+        "fc2_gemm": T * HID * e + HID * D * e + T * D * 4 * 2 + (0 if prec.startswith("slab") else T * D * e),
         "proj_gemm": T * D * e + D * D * e + T * D * 4 * 2 + T * D * e,
         "qkv_gemm": T * D * e + D * 3 * D * e + qkv_out,
         "attention": qkv_out + T * D * e,
