@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Workgroups per CU the runtime grants the main split-bf16 kernels (hipOccupancyMaxActiveBlocksPerMultiprocessor).
+Development tool, GPU box only; needs the stamps build: `make -C vit-ocm-wmsegmentation_amd/csrc stamps`."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
 os.environ["OCM_VIT_LIB"] = os.path.join(os.getcwd(), "exp_libs", "stamps.so")
