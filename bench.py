@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — OCM tiles/s of the ViT attention-map hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1: starts its own N ranks, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -172,6 +172,21 @@ def slab_sweep(args, dev, world, rank, lib):
             "path_tflops": round(T / dt * fwin / 1e12, 2), "roofline": roof}
 
 
+def self_launch(n):
+    """Run this script as n ranks under torch.distributed.run on 127.0.0.1 (a free port) and return their exit status."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,12 +205,17 @@ def main():
     ap.add_argument("--breakdown", action="store_true", help="print a per-kernel-class table to stderr")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started directly: become the launcher. Nothing in this process has touched HIP yet
+        # (importing torch does not), so the N ranks are fresh children of torch.distributed.run, one per GPU; their
+        # stdout is ours (rank 0 prints the JSON line) and their exit status is ours.
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python bench.py --gpus N does that itself)")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device")
     # one rank per GPU (RCCL). OCM_BENCH_BACKEND=gloo lets the N>1 code path be rehearsed on a 1-GPU box
@@ -316,22 +336,24 @@ def main():
             dist.destroy_process_group()
         return
 
-    # parity of what was just timed: attention-map L_inf vs the CPU oracle on the first tiles of the bench batch, for the
-    # random-init weights of the timed run and for the sharp (qkv x4) and peaked (qkv x8, attention max ~0.8: what a
-    # trained checkpoint looks like) weight sets pushed through the same engine at the same batch
+    # parity of what was just timed: attention-map L_inf vs the CPU oracle on the FIRST, MIDDLE and LAST tile of the bench
+    # batch (a remap or batch-stride slip on later images must show), for the random-init weights of the timed run and for
+    # the sharp (qkv x4) and peaked (qkv x8, attention max ~0.8: what a trained checkpoint looks like) weight sets pushed
+    # through the same engine at the same batch
     from oracle import vit_oracle as O  # checker
-    nchk = min(2, B)
+    pick = sorted({0, B // 2, B - 1})
     linf_by_set = {}
     for variant in ("init", "sharp", "peaked"):
         sd = synth.synth_arch_state_dict(args.arch, p, seed=0, variant=variant)
         cfg = O.make_cfg(sd, p, H)
-        ref = O.get_last_selfattention(sd, cfg, x[:nchk].cpu())
+        ref = O.get_last_selfattention(sd, cfg, x[pick].cpu())
         if variant == "init":
-            got = out["attn"][0][:nchk]
+            got = out["attn"][0][pick]
         else:
             model.load_state_dict(sd)
-            got = model._run(x, flags=flags)["attn"][0][:nchk]
-        linf_by_set[variant] = {"linf": float((got.cpu() - ref).abs().max()), "attn_max": round(float(ref.max()), 4)}
+            got = model._run(x, flags=flags)["attn"][0][pick]
+        linf_by_set[variant] = {"linf": float((got.cpu() - ref).abs().max()), "attn_max": round(float(ref.max()), 4),
+                                "tiles_checked": pick}
     linf = linf_by_set["init"]["linf"]
 
     # HBM bytes per launch of the dominant class: measured offline with rocprofv3 --pmc (separate passes,
@@ -349,8 +371,8 @@ def main():
         model.set_precision("bf16")
         ob = model._run(x, flags=flags)
         sdp = synth.synth_arch_state_dict(args.arch, p, seed=0, variant="peaked")
-        refp = O.get_last_selfattention(sdp, O.make_cfg(sdp, p, H), x[:nchk].cpu())
-        peaked_bf16 = float((ob["attn"][0][:nchk].cpu() - refp).abs().max())
+        refp = O.get_last_selfattention(sdp, O.make_cfg(sdp, p, H), x[pick].cpu())
+        peaked_bf16 = float((ob["attn"][0][pick].cpu() - refp).abs().max())
         for _ in range(3):
             model._run(x, flags=flags)
         torch.cuda.synchronize()

@@ -262,6 +262,11 @@ def main():
         return run_wrappers()
     if "--only-helpers" in sys.argv:
         return run_helpers()
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv if a.startswith("--cases=")]
+    if only:  # e.g. --cases=vitb16_384_sharp,vits8_384_peaked : write just these model fixtures
+        for name in only[0]:
+            run_case(name, CASES[name])
+        return
     run_helpers()
     run_wrappers()
     for name, case in CASES.items():

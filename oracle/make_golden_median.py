@@ -6,25 +6,15 @@ import os
 import sys
 
 import numpy as np
-from scipy.ndimage import median_filter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import vit_oracle as O  # noqa: E402
-
-SIZES = (2, 3, 4, 5, 7)
-
-
-def inputs(seed=17):
-    rng = np.random.default_rng(seed)
-    smooth = rng.random((2, 6, 5), dtype=np.float32)
-    up = np.repeat(np.repeat(smooth, 4, axis=1), 4, axis=2)  # block-constant like a nearest-upsampled attention map
-    noisy = rng.random((2, 24, 20), dtype=np.float32)
-    noisy[0, 3:9, 2:7] = 0.5  # ties
-    return np.concatenate([up, noisy], 0)
+from tests.golden_cases import MEDIAN_SIZES as SIZES, median_inputs as inputs  # noqa: E402  (scipy-free, shared with the tests)
 
 
 def main():
+    from scipy.ndimage import median_filter  # only the fixture writer needs scipy
     x = inputs()
     out = {"seed": np.int64(17)}
     import scipy

@@ -60,8 +60,14 @@ def test_layernorm_split_out(lib, dev, rows, dim):
     assert (err <= ref.abs() * 2 ** -16 + 2e-5).all(), err.max().item()  # fp32 LayerNorm, then 2^-17 pairs
 
 
+# The shapes reach every split-bf16 GEMM the BASELINE configurations dispatch (kernels_gemm.hip::launch_linear_mode):
+#   (12608, 1536, 384)  config 2 fc1: 1188 tiles -> gemm_dma_kernel<128x128>, two workgroups per CU
+#   (12608, 384, *)     config 2 proj / fc2 un-fused: 64x128 register-staged
+#   (32768, 1024, 768)  config 3: 512 tiles of 256x256 -> gemm_dma_kernel<256x256>, banded epilogue
+#   (24576, 384, 1536)  config 4 fc2 at 10-11 windows per forward and up: 576 tiles -> un-fused gemm_dma_kernel<128x128>, K = 48 steps
+#   (1000 / 333 / 70 / 64 rows): the one-tile-per-call DMA kernels (64x128 two-stage, 64x64 four-stage) and tails
 @pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (12608, 1536, 384), (333, 384, 1536), (70, 96, 192),
-                                   (12608, 384, 384), (64, 192, 64)])
+                                   (12608, 384, 384), (64, 192, 64), (32768, 1024, 768), (24576, 384, 1536)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_linear_x3(lib, dev, M, N, K, epi):
     a = _rand((M, K), dev, 40)
@@ -86,7 +92,9 @@ def test_linear_x3(lib, dev, M, N, K, epi):
     assert (got.double() - ref).abs().max().item() < 3e-5 * max(1.0, math.sqrt(K) / 8)
 
 
-@pytest.mark.parametrize("B,N,H", [(3, 197, 6), (2, 17, 2), (1, 577, 12), (5, 50, 3)])
+# (64, 197, 6): config 2, 891 tiles of 128x128 -> qkv_dma_kernel<Cfg128x128q> (8 waves); (26, 577, 12): ViT-B rows enough
+# for big_tiles_pay -> qkv_dma_kernel<Cfg256x256> (config 3's kernel); the others: 64x128 DMA (M <= 1024) and tails
+@pytest.mark.parametrize("B,N,H", [(3, 197, 6), (2, 17, 2), (1, 577, 12), (5, 50, 3), (64, 197, 6), (26, 577, 12)])
 def test_qkv_proj_x3(lib, dev, B, N, H):
     D = H * 64
     a, w, bias = _rand((B * N, D), dev, 50), _rand((3 * D, D), dev, 51, 0.05), _rand((3 * D,), dev, 52, 0.1)
@@ -110,8 +118,10 @@ def test_qkv_proj_x3(lib, dev, B, N, H):
 
 
 @pytest.mark.parametrize("B,N,H", [(2, 197, 6), (1, 17, 2), (1, 577, 3), (1, 64, 1), (1, 65, 1), (1, 2305, 2),
-                                   (1, 5, 1), (1, 32, 2), (1, 33, 1), (1, 1024, 1), (1, 1025, 1)])  # one tile, no padding,
-# one key into the second tile, the 4-wave / 8-wave switch
+                                   (1, 5, 1), (1, 32, 2), (1, 33, 1), (1, 1024, 1), (1, 1025, 1),  # one tile, no padding,
+                                   # one key into the second tile, the 4-wave / 8-wave switch
+                                   (64, 197, 6),   # config 2's launch: 768 workgroups through xcd_remap2, EVERY (b, h) compared
+                                   (3, 2305, 6)])  # config 4's shape per window, several images: batch strides of the 8-wave kernel
 @pytest.mark.parametrize("sharp", [1.0, 3.0])
 def test_attention_x3(lib, dev, B, N, H, sharp):
     g = torch.Generator().manual_seed(60)

@@ -5,6 +5,7 @@ import pytest
 import torch
 
 from oracle import vit_oracle as O
+from tests.golden_cases import SATURATED
 from tests.helpers import CASES, case_dims, case_inputs, case_state_dict, load_golden
 
 # fp32 CPU arithmetic re-run on possibly different host cores / thread counts: summation order of
@@ -23,8 +24,11 @@ def test_oracle_matches_reference_golden(name):
         n = case["n"]
         feat, attns, qkvs = O.get_intermediate_feat(sd, cfg, x, n)
         a = attns[-1]
-        np.testing.assert_allclose(a[:, :, 0, 1:].numpy(), gold[pfx + "cls_rows"], rtol=0, atol=TOL)
-        np.testing.assert_allclose(a[:, :, a.shape[-1] // 2, :].numpy(), gold[pfx + "mid_rows"], rtol=0, atol=TOL)
+        # the saturated set is ill-conditioned: another summation order of the same fp32 arithmetic (other core count /
+        # BLAS blocking) moves it by up to ~5e-4 (fp32 vs float64: tools/precision_study.py)
+        atol = 2e-3 if name in SATURATED else TOL
+        np.testing.assert_allclose(a[:, :, 0, 1:].numpy(), gold[pfx + "cls_rows"], rtol=0, atol=atol)
+        np.testing.assert_allclose(a[:, :, a.shape[-1] // 2, :].numpy(), gold[pfx + "mid_rows"], rtol=0, atol=atol)
         assert np.array_equal(a[:, :, 0, 1:].mean(1).argmax(-1).numpy(), gold[pfx + "argmax"])  # indices: exact
         np.testing.assert_allclose(feat[-1][:, :4, :16].numpy(), gold[pfx + "feat_head"], rtol=0, atol=10 * TOL)
         assert abs(float(feat[-1].double().abs().sum()) / float(gold[pfx + "feat_abssum"]) - 1) < 1e-5
@@ -104,7 +108,7 @@ def test_median_filter_restatement_equals_scipy_fixture():
     oracle/make_golden_median.py; when scipy is importable where the tests run, against scipy itself too."""
     import numpy as np
     from oracle import vit_oracle as O
-    from oracle.make_golden_median import SIZES, inputs
+    from tests.golden_cases import MEDIAN_SIZES as SIZES, median_inputs as inputs
     from tests.helpers import load_golden
     gold = load_golden("median")
     x = inputs(int(gold["seed"]))

@@ -201,7 +201,7 @@ def test_segment_images_matches_oracle_chain(dev, precision):
 def test_median_filter_bit_exact_vs_scipy_fixture(dev, lib):
     """ocm_op_median_filter against outputs of the real scipy.ndimage.median_filter (tests/golden/median.npz)."""
     import ctypes as C
-    from oracle.make_golden_median import SIZES, inputs
+    from tests.golden_cases import MEDIAN_SIZES as SIZES, median_inputs as inputs
     gold = load_golden("median")
     x = torch.from_numpy(inputs(int(gold["seed"]))).to(dev)
     for k in SIZES:

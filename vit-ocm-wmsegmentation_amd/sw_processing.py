@@ -294,6 +294,10 @@ class SlidingWindowAttention:
         pad_w += (-(slab.shape[2] + pad_w)) % 4
         if pad_h or pad_w or slab.shape[2] % 4:
             slab = torch.nn.functional.pad(slab, (0, pad_w, 0, pad_h)).contiguous()
+        elif slab.stride(1) % 4 or slab.stride(0) % 4 or slab.data_ptr() % 16:
+            # a view whose rows are unit-stride but do not START on 16-byte boundaries (big[:, :, 1:4097], odd row
+            # pitch): the gather's float4 loads need aligned rows, so take an aligned copy
+            slab = slab.contiguous()
         world = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
         rank = dist.get_rank(self.group) if world > 1 else 0
         begin, end, share = shard_range(T, world, rank)

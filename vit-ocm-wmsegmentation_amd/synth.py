@@ -16,6 +16,9 @@ effectively untruncated), conv weight/bias ~ U(+-1/sqrt(fan_in)) (PyTorch Conv2d
             uniform, max ~0.006, and hides precision bugs — SURVEY §7-1); attention max ~0.013
   "peaked": "full" with attn.qkv weights x8: attention max ~0.79, CLS-row max ~0.40 (ViT-S/16) —
             the precision stress set
+  "qkv<g>": "full" with attn.qkv weights x g (e.g. "qkv6.5"): the gain that gives attention max ~0.8 depends on the
+            embedding width and the token count (ViT-B/16 at 384^2: 6.5 -> 0.84; ViT-S/8 at 384^2: 10 -> 0.90), and
+            x8 saturates ViT-B's softmax (max 1.0000: the fp32 reference itself is then only good to 5e-4)
 """
 import zlib
 
@@ -68,10 +71,23 @@ def param_shapes(embed_dim, depth, patch_size, in_chans=3, mlp_ratio=4.0, img_si
     return shapes
 
 
+def qkv_gain_of(variant):
+    """Factor applied to the attn.qkv weights by `variant` (raises on an unknown variant)."""
+    if variant in ("init", "full"):
+        return 1.0
+    if variant in ("sharp", "peaked"):
+        return 4.0 if variant == "sharp" else 8.0
+    if variant.startswith("qkv"):
+        try:
+            return float(variant[3:])
+        except ValueError:
+            pass
+    raise ValueError(f"unknown variant {variant!r}")
+
+
 def synth_state_dict(embed_dim, depth, patch_size, *, seed=0, variant="full", in_chans=3, mlp_ratio=4.0,
                      img_size=224):
-    if variant not in ("init", "full", "sharp", "peaked"):
-        raise ValueError(f"unknown variant {variant!r}")
+    gain = qkv_gain_of(variant)
     sd = {}
     for name, shape in param_shapes(embed_dim, depth, patch_size, in_chans, mlp_ratio, img_size).items():
         if name.startswith("patch_embed.proj"):
@@ -88,8 +104,8 @@ def synth_state_dict(embed_dim, depth, patch_size, *, seed=0, variant="full", in
             t = torch.zeros(shape) if variant == "init" else _normal(seed, name, shape, 0.02)
         else:
             t = _normal(seed, name, shape, 0.02)
-            if variant in ("sharp", "peaked") and name.endswith("attn.qkv.weight"):
-                t = t * (4.0 if variant == "sharp" else 8.0)
+            if gain != 1.0 and name.endswith("attn.qkv.weight"):
+                t = t * gain
         sd[name] = t
     return sd
 
