@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCM_ABI_VERSION 5
+#define OCM_ABI_VERSION 6
 
 enum {
     OCM_OK = 0,
@@ -94,6 +94,13 @@ void ocm_vit_destroy(ocm_vit_t *h);
  * for vectors) copy, so the source may be freed after the stream has run. */
 int ocm_vit_set_param(ocm_vit_t *h, const char *name, const float *dev_src, size_t count,
                       void *stream);
+/* Per-handle dispatch options (this handle only; no process-wide state). 0 is always "automatic".
+ *   OCM_OPT_FUSE_LN  attn.proj / mlp.fc2 + residual fused with the LayerNorm that follows (one full-row kernel, bit
+ *                    identical to the GEMM + LayerNorm pair): 0 = where it is faster (>= 8192 token rows and fewer than
+ *                    512 tiles of 128 x 128 in the output), 1 = never, 2 = whenever the embedding width has the kernel
+ *                    (ocm_linear_resid_ln_supported). */
+enum { OCM_OPT_FUSE_LN = 0, OCM_OPT_COUNT = 1 };
+int ocm_vit_set_option(ocm_vit_t *h, int32_t option, int32_t value);
 /* 0 when every parameter has been set, else OCM_ESTATE with the first missing
  * name in ocm_last_error(). */
 int ocm_vit_params_ready(const ocm_vit_t *h);
@@ -211,7 +218,7 @@ int ocm_op_linear(int32_t precision, const void *a, const void *w, const float *
 /* nn.Linear + residual + LayerNorm in one kernel (Block.forward :107-111 with the NEXT normalisation folded in:
  *   x = resid + A[M][K] · W[D][K]^T + bias;   xn = LayerNorm(x; gamma, beta, eps) in the activation type E
  * exactly as ocm_op_linear (epilogue RESID_F32) followed by ocm_op_layernorm would produce them (bit for bit).
- * A workgroup owns whole rows, so D is one of 128 / 256 / 384 / 512 (ocm_linear_resid_ln_supported). resid may
+ * A workgroup owns whole rows, so D is one of 128 / 256 / 384 (ocm_linear_resid_ln_supported). resid may
  * alias x. The engine uses it for attn.proj -> norm2 and mlp.fc2 -> the next block's norm1 when M >= 8192. */
 int ocm_linear_resid_ln_supported(int32_t D);
 int ocm_op_linear_resid_ln(int32_t precision, const void *a, const void *w, const float *bias, const float *resid,
@@ -270,9 +277,6 @@ enum {
     OCM_K_COUNT = 8
 };
 int ocm_prof_begin(uint32_t class_mask, int32_t max_launches);
-/* Development knobs (microbenchmarks only; 0 = shipped behaviour): knob 0 overrides the GEMM kernel variant of
- * ocm_op_linear (tools/microbench_x3.py). Process-wide, not thread-safe. */
-int ocm_debug_knob(int32_t which, int32_t value);
 int ocm_prof_end(double *ms_per_class /*[OCM_K_COUNT]*/, int64_t *launches_per_class /*[OCM_K_COUNT]*/);
 
 /* ---- sliding-window post-processing on device (SURVEY §8-f "next" rows 1-2; sw_processing.py) ---- */

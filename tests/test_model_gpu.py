@@ -263,20 +263,26 @@ def test_sliding_window_single_rank(dev):
 @pytest.mark.parametrize("precision", ["bf16x3", "bf16", "fp32"])
 def test_fused_gemm_layernorm_is_bit_identical(dev, lib, name, precision):
     """proj / fc2 + residual + the following LayerNorm in one kernel (engine default for T >= 8192 rows, forced here
-    through the development knob) against the separate GEMM and LayerNorm launches: same accumulation order, same
-    two-pass statistics on the same fp32 values -> identical bits in every output."""
+    through the per-handle option OCM_OPT_FUSE_LN) against the separate GEMM and LayerNorm launches: same accumulation
+    order, same two-pass statistics on the same fp32 values -> identical bits in every output."""
     case = CASES[name]
     model = build_module(case, dev).set_precision(precision)
     x = case_inputs(case)[0].to(dev)
+    eng = model._engine(dev)
     try:
-        assert lib.ocm_debug_knob(5, 1) == 0  # never fuse
+        eng.set_fuse_layernorm("never")
         f0, a0, q0 = model.get_intermediate_feat(x, 2)
         l0 = model.get_last_selfattention(x)
-        assert lib.ocm_debug_knob(5, 2) == 0  # always fuse
+        eng.set_fuse_layernorm("always")
         f1, a1, q1 = model.get_intermediate_feat(x, 2)
         l1 = model.get_last_selfattention(x)
     finally:
-        lib.ocm_debug_knob(5, 0)
+        eng.set_fuse_layernorm("auto")
+    with pytest.raises(ValueError):
+        lib.ocm_vit_set_option.errcheck = None
+        from vit_ocm_wmsegmentation_amd import _lib as L
+        L.check(lib.ocm_vit_set_option(eng._h, 7, 0))  # unknown option
+    assert not hasattr(lib, "ocm_debug_knob") or "OCM_VIT_LIB" in __import__("os").environ  # product build: no knobs
     for u, v in zip(f0 + a0 + q0 + [l0], f1 + a1 + q1 + [l1]):
         assert torch.equal(u, v)
 

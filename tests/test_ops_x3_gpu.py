@@ -161,13 +161,14 @@ def test_attention_x3(lib, dev, B, N, H, sharp):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32", "bf16x3"])
-@pytest.mark.parametrize("M,D,K", [(1000, 384, 384), (12608, 384, 1536), (70, 128, 192), (333, 512, 512), (64, 256, 64)])
+@pytest.mark.parametrize("M,D,K", [(1000, 384, 384), (12608, 384, 1536), (70, 128, 192), (333, 256, 512), (64, 256, 64)])
 def test_linear_resid_ln_equals_linear_then_layernorm(lib, dev, prec, M, D, K):
     """ocm_op_linear_resid_ln (one kernel: GEMM + bias + residual, then LayerNorm of the rows it has just produced) is
     bit for bit ocm_op_linear(RESID_F32) followed by ocm_op_layernorm, in every precision mode, and sits where the
     float64 reference says (Block.forward, dino/vision_transformer.py:107-111)."""
     pc = _lib.PRECISIONS[prec]
     assert lib.ocm_linear_resid_ln_supported(D) == 1 and lib.ocm_linear_resid_ln_supported(96) == 0
+    assert lib.ocm_linear_resid_ln_supported(512) == 0  # its split-bf16 tile would spill: not offered
     a, w = _rand((M, K), dev, 70), _rand((D, K), dev, 71, 0.05)
     bias, resid = _rand((D,), dev, 72, 0.1), _rand((M, D), dev, 73)
     gamma, beta = _rand((D,), dev, 74) * 0.1 + 1, _rand((D,), dev, 75) * 0.1

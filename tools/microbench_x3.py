@@ -9,6 +9,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the knobs exist in the development build only (`make -C vit-ocm-wmsegmentation_amd/csrc dev`)
+os.environ.setdefault("OCM_VIT_LIB", os.path.join(ROOT, "exp_libs", "libocm_vit_dev.so"))
 import torch  # noqa: E402
 
 from vit_ocm_wmsegmentation_amd import _lib  # noqa: E402

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OCM_VIT_LIB lets kernel experiments A/B two builds of the same ABI; the default is the in-tree build.
 LIB_PATH = os.environ.get("OCM_VIT_LIB") or os.path.join(_HERE, "libocm_vit.so")
 
-OCM_ABI_VERSION = 5
+OCM_ABI_VERSION = 6
 OCM_OK, OCM_EINVAL, OCM_ESTATE, OCM_EHIP, OCM_ENOMEM, OCM_ENAME = 0, 1, 2, 3, 4, 5
 
 OCM_PREC_BF16 = 0
@@ -19,6 +19,7 @@ OCM_PREC_BF16X3 = 2
 PRECISIONS = {"bf16": OCM_PREC_BF16, "fp32": OCM_PREC_FP32, "bf16x3": OCM_PREC_BF16X3}
 DEFAULT_PRECISION = "bf16x3"  # the mode that holds the north star's 1e-3 on every golden weight set
 OCM_LN_F32, OCM_LN_BF16, OCM_LN_SPLIT = 0, 1, 2
+OCM_OPT_FUSE_LN = 0  # ocm_vit_set_option: 0 auto, 1 never, 2 always
 
 OCM_OUT_FEAT = 1 << 0
 OCM_OUT_ATTN = 1 << 1
@@ -155,7 +156,7 @@ SIGNATURES = {
     "ocm_op_head_mean": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_image_to_gray_u8": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp]),
     "ocm_op_blend_u8": (C.c_int, [_vp, _vp, _i64, C.c_double, C.c_double, _vp, _vp, _vp]),
-    "ocm_debug_knob": (C.c_int, [_i32, _i32]),
+    "ocm_vit_set_option": (C.c_int, [C.c_void_p, _i32, _i32]),
     "ocm_prof_begin": (C.c_int, [C.c_uint32, _i32]),
     "ocm_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(_i64)]),
     "ocm_sw_count": (_i32, [_i32, _i32]),
@@ -190,11 +191,17 @@ def load():
         fn.argtypes = args
     if lib.ocm_abi_version() != OCM_ABI_VERSION:
         raise OcmError(f"libocm_vit ABI {lib.ocm_abi_version()} != binding ABI {OCM_ABI_VERSION}")
-    # development: OCM_KNOBS="0=4,3=-1" presets ocm_debug_knob values (A/B runs of kernel variants)
-    for item in filter(None, os.environ.get("OCM_KNOBS", "").split(",")):
-        which, value = item.split("=")
-        if lib.ocm_debug_knob(int(which), int(value)) != OCM_OK:
-            raise OcmError(f"OCM_KNOBS: bad entry {item!r}")
+    # development build only (include/ocm_vit_dev.h, loaded through OCM_VIT_LIB): the kernel-variant knobs; OCM_KNOBS="0=4,3=-1"
+    # presets them for A/B runs. The product library exports neither.
+    if hasattr(lib, "ocm_debug_knob"):
+        lib.ocm_debug_knob.restype, lib.ocm_debug_knob.argtypes = C.c_int, [_i32, _i32]
+        for item in filter(None, os.environ.get("OCM_KNOBS", "").split(",")):
+            which, value = item.split("=")
+            if lib.ocm_debug_knob(int(which), int(value)) != OCM_OK:
+                raise OcmError(f"OCM_KNOBS: bad entry {item!r}")
+    elif os.environ.get("OCM_KNOBS"):
+        raise OcmError("OCM_KNOBS is set but the loaded library is the product build (no ocm_debug_knob): "
+                       "`make -C csrc dev` and point OCM_VIT_LIB at exp_libs/libocm_vit_dev.so")
     _lib = lib
     return lib
 

@@ -10,6 +10,7 @@
 
 #include "host_common.h"
 #include "launch.h"
+#include "dev_knobs.h"
 
 static thread_local std::string g_err;
 
@@ -90,12 +91,13 @@ extern "C" int ocm_prof_end(double *ms_per_class, int64_t *launches_per_class) {
     return rc;
 }
 
-extern int g_ocm_knobs[8];
+#ifdef OCM_DEV  // development build only: include/ocm_vit_dev.h
 extern "C" int ocm_debug_knob(int32_t which, int32_t value) {
     if (which < 0 || which >= 8) return fail(OCM_EINVAL, "knob %d out of range", which);
     g_ocm_knobs[which] = value;
     return OCM_OK;
 }
+#endif
 
 extern "C" int ocm_abi_version(void) { return OCM_ABI_VERSION; }
 extern "C" const char *ocm_last_error(void) { return g_err.c_str(); }
@@ -137,6 +139,7 @@ struct ocm_vit {
     ocm_vit_io graph_key;
     bool graph_valid = false;
     uint64_t graph_hits = 0, graph_captures = 0;
+    int32_t opt[OCM_OPT_COUNT] = {0};  // ocm_vit_set_option: per-handle dispatch options (0 = automatic)
 
     int add(const std::string &name, ParamKind kind, size_t count, size_t stored_elems) {
         Param pr{name, kind, count, arena_bytes, false};
@@ -262,6 +265,15 @@ extern "C" int ocm_vit_set_param(ocm_vit_t *h, const char *name, const float *de
     return fail(OCM_ENAME, "unknown parameter '%s'", name);
 }
 
+extern "C" int ocm_vit_set_option(ocm_vit_t *h, int32_t option, int32_t value) {
+    if (!h) return fail(OCM_EINVAL, "null handle");
+    if (option < 0 || option >= OCM_OPT_COUNT) return fail(OCM_EINVAL, "unknown option %d", option);
+    if (option == OCM_OPT_FUSE_LN && (value < 0 || value > 2)) return fail(OCM_EINVAL, "OCM_OPT_FUSE_LN takes 0 (auto), 1 (never) or 2 (always)");
+    if (h->opt[option] != value) h->graph_valid = false;  // a cached launch sequence was recorded under the old setting
+    h->opt[option] = value;
+    return OCM_OK;
+}
+
 extern "C" int ocm_vit_params_ready(const ocm_vit_t *h) {
     if (!h) return fail(OCM_EINVAL, "null handle");
     for (const Param &pr : h->params)
@@ -342,12 +354,13 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     const int pc = h->prec, lnk = ln_kind_of_prec(pc);
     // The fused GEMM + LayerNorm kernel owns full rows (64 x D tiles, D / 128 times the W bytes per workgroup and step):
     // it pays once there are enough row tiles to occupy the chip (measured: +2 % at T = 12 608; at T = 197, four
-    // workgroups stream all of W each: 1.52 ms per forward against 1.14 ms). Knob 5: 1 = never, 2 = always.
+    // workgroups stream all of W each: 1.52 ms per forward against 1.14 ms). Handle option OCM_OPT_FUSE_LN: 1 = never,
+    // 2 = always.
     // Above 512 tiles of 128 x 128 in the (T x D) output the un-fused pair wins again: those tiles fill two workgroups
     // per CU and move half the LDS bytes per MFMA of a 64-row tile (ViT-S/8 slab sweep, T = 48 405: 575 -> 556 ms).
     const long t128 = (long)((T + 127) / 128) * (D / 128);
-    const bool fuse_ln = linear_resid_ln_supported(D) && g_ocm_knobs[5] != 1 &&
-                         ((T >= 8192 && t128 < 512) || g_ocm_knobs[5] == 2);
+    const int fuse_opt = h->opt[OCM_OPT_FUSE_LN];
+    const bool fuse_ln = linear_resid_ln_supported(D) && fuse_opt != 1 && ((T >= 8192 && t128 < 512) || fuse_opt == 2);
     if (xn_out) *xn_out = false;
     // y = attn(norm1(x))
     if (!xn_ready) { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, lnk, T, D, eps, s)); }
@@ -651,7 +664,7 @@ extern "C" int ocm_op_linear_resid_ln(int32_t precision, const void *a, const vo
     int pc = 0, rc = prec_of(precision, &pc);
     if (rc) return rc;
     if (!a || !w || !resid || !x || !gamma || !beta || !xn) return fail(OCM_EINVAL, "null argument");
-    if (!linear_resid_ln_supported(D)) return fail(OCM_EINVAL, "row width %d not in {128, 256, 384, 512}", D);
+    if (!linear_resid_ln_supported(D)) return fail(OCM_EINVAL, "row width %d not in {128, 256, 384}", D);
     if (M <= 0 || K <= 0 || K % 64) return fail(OCM_EINVAL, "bad shape M=%d K=%d (K%%64)", M, K);
     HIP_TRY(launch_linear_resid_ln(pc, a, w, bias, resid, x, gamma, beta, xn, M, D, K, eps, (hipStream_t)stream));
     return OCM_OK;

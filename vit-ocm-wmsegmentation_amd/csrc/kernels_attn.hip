@@ -30,6 +30,7 @@
 
 #define LOG2E 1.4426950408889634f
 int ocm_wt_mask();  // kernels_gemm.hip
+#include "dev_knobs.h"
 #define OCM_VMCNT_ATTN(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 template <bool WANT_O>
@@ -1395,11 +1396,11 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
     const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
     if (prec == 2) {
         if (n_pad % 32) return hipErrorInvalidValue;
-        extern int g_ocm_knobs[8];
         // Whole-sequence kernel (all K / V^T of a head in LDS, one DMA burst): built, parity-green, and measured SLOWER
         // than the streaming kernel at ViT-S/16, B = 64 (40.3 us against 34.1 us per launch: 128 KiB of LDS leaves one
         // workgroup per CU, so nothing overlaps the fill) — kept behind knob 6 = 2 for A/B runs, not dispatched.
-        if (n_tokens <= 256 && g_ocm_knobs[6] == 2) {
+#ifdef OCM_DEV
+        if (n_tokens <= 256 && OCM_KNOB(6) == 2) {
             const int nt = (n_tokens + 63) / 64, lds = nt * 2 * 16384;
             static unsigned long long optin[2] = {0, 0};
             int dev = 0;
@@ -1421,8 +1422,9 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
                                                                 lse2, n_tokens, n_pad, heads, scale * LOG2E);
             return hipGetLastError();
         }
+#endif
         // long sequences: 8 waves per workgroup share each K / V^T tile (half the L2 -> LDS traffic per query)
-        const bool wide = (n_tokens > 1024 && g_ocm_knobs[7] != 1) || g_ocm_knobs[7] == 2;
+        const bool wide = (n_tokens > 1024 && OCM_KNOB(7) != 1) || OCM_KNOB(7) == 2;
         const dim3 grid8((qtiles + 7) / 8, batch * heads), block8(512);
 #define OCM_X3_ATTN(WO, NW_, G, B_)                                                                                      \
     attn_fwd_x3_kernel<WO, NW_><<<G, B_, 0, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx, lse2, \
@@ -1431,13 +1433,16 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
     attn_fwd_x3_dma_kernel<WO, NW_, WPS_><<<G, B_, 0, s>>>((const char *)q, (const char *)k, (const char *)vt,          \
                                                            (char *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E,    \
                                                            (ocm_wt_mask() >> 4) & 1)
-        if (g_ocm_knobs[6] == 1) {  // the register-staged streaming kernel (A/B runs)
+#ifdef OCM_DEV
+        if (OCM_KNOB(6) == 1) {  // the register-staged streaming kernel (A/B runs)
             if (wide) {
                 if (ctx) OCM_X3_ATTN(true, 8, grid8, block8); else OCM_X3_ATTN(false, 8, grid8, block8);
             } else {
                 if (ctx) OCM_X3_ATTN(true, 4, grid, block); else OCM_X3_ATTN(false, 4, grid, block);
             }
-        } else if (wide) {
+        } else
+#endif
+        if (wide) {
             if (ctx) OCM_X3_ATTN_DMA(true, 8, 2, grid8, block8); else OCM_X3_ATTN_DMA(false, 8, 2, grid8, block8);
         } else {
             if (ctx) OCM_X3_ATTN_DMA(true, 4, 3, grid, block); else OCM_X3_ATTN_DMA(false, 4, 3, grid, block);

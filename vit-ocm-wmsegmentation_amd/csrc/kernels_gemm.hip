@@ -1,309 +1,36 @@
-// kernels_gemm.hip — the four GEMM-shaped stages of the ViT forward on MFMA:
-//   patch embedding  (PatchEmbed.forward, dino/vision_transformer.py:129-132 + prepare_tokens :198-209)
-//   qkv projection   (Attention.forward :80)
-//   proj / fc2 + residual (Attention.forward :88, Block.forward :110-111, Mlp.forward :61)
-//   fc1 + exact-erf GELU  (Mlp.forward :58-59)
-// All share gemm_core.h's main loop; they differ in the A loader and the epilogue. Every kernel exists
-// for two operand element types: bf16 (OCM_PREC_BF16) and float (OCM_PREC_FP32, exact-fp32 MFMA).
-#include "gemm_core.h"
+// kernels_gemm.hip — precision dispatch of the GEMM-shaped stages (launch.h) onto the per-element-type launchers of
+// gemm_kernels.h, whose instantiations are compiled in kernels_gemm_inst.hip. Holds the process-wide bits: the
+// write-through store mask and, in development builds only, the kernel-variant knobs.
 #include "launch.h"
+#include "dev_knobs.h"
 
-typedef GemmCfg<128, 128, 2, 2> Cfg128x128;
-// the qkv projection runs the same tile with 8 waves (32x64 MFMA sub-tiles per wave): two waves per SIMD inside
-// one workgroup overlap its heavier scatter epilogue with the other waves' MFMAs (29.0 -> 25.8 us at ViT-S, B=64)
-typedef GemmCfg<128, 128, 2, 4> Cfg128x128q;
-typedef GemmCfg<64, 128, 2, 2> Cfg64x128;
-typedef GemmCfg<64, 64, 2, 2> Cfg64x64;
-// 8 waves, one workgroup per CU: half the L2->LDS bytes per output element of 128x128. Pays off once the
-// problem has at least two full rounds of such tiles (ViT-B at 384^2, the ViT-S/8 slab windows); below
-// that the idle CUs of the last round cost more than the traffic saves, and with K = 384 (six steps) the
-// exposed prologue of a lone workgroup does (measured: ViT-S/8 slab fc1 +7 % slower, ViT-B GEMMs 13 % faster).
-typedef GemmCfg<256, 256, 2, 4> Cfg256x256;
+// entry templates of gemm_kernels.h (defined and explicitly instantiated in kernels_gemm_inst.hip)
+template <class E>
+hipError_t launch_linear_e(const E *a, const E *w, const float *bias, const float *resid, void *out, int M, int N, int K,
+                           int epilogue, hipStream_t s);
+template <class E>
+hipError_t launch_linear_ld_e(const E *a, int64_t lda, const E *w, const float *bias, const float *resid, void *out,
+                              int64_t ldo, int M, int N, int K, int epilogue, hipStream_t s);
+template <class E>
+hipError_t launch_resid_ln_e(const E *a, const E *w, const float *bias, const float *resid, float *x, const float *gamma,
+                             const float *beta, void *xn, int M, int D, int K, float eps, hipStream_t s);
+template <class E>
+hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E *vt, float *qkv_f32, int batch,
+                        int n_tokens, int n_pad, int heads, int head_dim, bool want_v, hipStream_t s);
+template <class E>
+hipError_t launch_patch_e(const PatchArgs &pa, const E *w, const float *bias, const float *pos, float *x, int dim,
+                          hipStream_t s);
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: remember per kernel template
-// instantiation (one static mask each) on which devices it has been set.
-static hipError_t ensure_lds_optin(const void *kern, int bytes, unsigned long long &done_mask) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (done_mask & bit) return hipSuccess;  // benign race: setting twice is idempotent
-    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e == hipSuccess) done_mask |= bit;
-    return e;
-}
-
-// development knobs (ocm_debug_knob; 0 = shipped behaviour): [0] nn.Linear GEMM variant, [3] qkv GEMM variant,
-// [4] = 2 fused GEMM+LayerNorm on the LDS-DMA loop, [5] LayerNorm fusion 1 = never / 2 = always, [6] split-bf16
-// attention 1 = register-staged streaming kernel / 2 = whole-sequence kernel (shipped: LDS-DMA streaming kernel), [7] its
-// 8-wave form 1 = never / 2 = always. (A start-up stagger of co-resident workgroups was tried through knobs 1 / 2 and removed:
-// no gain at any delay)
+#ifdef OCM_DEV  // development build only (dev_knobs.h)
 int g_ocm_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 // Write-through (sc1) stores of streaming activation outputs, as a bit mask: 1 = nn.Linear activation outputs (fc1's
 // hidden tensor), 2 = q / k of the qkv projection, 4 = xn of the fused LayerNorm, 16 = attention context, 32 = x of the fused GEMM + LayerNorm; non-temporal loads of
 // the A rows of the full-row tiles (flat) and the nt policy on fc1's A-operand DMA (53.5 -> 63.4 us: the 12-fold reuse
 // of an A panel suffers) were tried too. Shipped: 1 | 2 | 32
 // (fc1 57.0 -> 54.2 us and +2.2 % end to end in alternating runs; qkv -0.7 us; x +0.6 % end to end; xn flat; the 8-byte
-// context stores get slower, 32 -> 39 us). Knob 1: 0 = shipped mask, -1 = none, any other value = that mask.
-int ocm_wt_mask() { return g_ocm_knobs[1] == 0 ? 35 : g_ocm_knobs[1] < 0 ? 0 : g_ocm_knobs[1]; }
-
-static inline bool big_tiles_pay(int M, int N, int K) {
-    return K >= 768 && N % 256 == 0 && (long)((M + 255) / 256) * (N / 256) >= 512;
-}
-
-// Store Elem<OE>::EPW consecutive activations (taken from fp32 values) at element column `col` of the row that
-// starts at `rowp`: 8 bf16 (16 B), 4 fp32 (16 B) or 8 split pairs (16 B of hi halves + 16 B of lo halves).
-__device__ __forceinline__ void store_act(bf16 *, char *rowp, int col, const f32x4 &v0, const f32x4 &v1) {
-    *(bf16x8 *)(rowp + col * 2) = cvt8(v0, v1);
-}
-__device__ __forceinline__ void store_act(float *, char *rowp, int col, const f32x4 &v0, const f32x4 &) {
-    *(f32x4 *)(rowp + col * 4) = v0;
-}
-__device__ __forceinline__ void store_act(sp32 *, char *rowp, int col, const f32x4 &v0, const f32x4 &v1) {
-    bf16x8 hi, lo;
-    split8(v0, v1, hi, lo);
-    *(bf16x8 *)(rowp + sp_off(col)) = hi;
-    *(bf16x8 *)(rowp + sp_off(col) + 64) = lo;
-}
-// Write-through (sc1) 16-byte store: the line leaves the XCD's L2 instead of staying in it. For outputs that are far
-// larger than the L2 and are not re-read by this kernel (fc1's 77 MB hidden tensor), plain stores evict the operands
-// the other workgroups of the XCD are still streaming. The trailing s_nop covers the store-data hazard hipcc cannot
-// see inside an asm statement.
-__device__ __forceinline__ void store16_wt(void *p, const bf16x8 &v) {
-    const f32x4 d = __builtin_bit_cast(f32x4, v);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(d) : "memory");
-}
-__device__ __forceinline__ void store_act_wt(sp32 *, char *rowp, int col, const f32x4 &v0, const f32x4 &v1) {
-    bf16x8 hi, lo;
-    split8(v0, v1, hi, lo);
-    store16_wt(rowp + sp_off(col), hi);
-    store16_wt(rowp + sp_off(col) + 64, lo);
-}
-template <class OE>
-__device__ __forceinline__ void store_act_wt(OE *t, char *rowp, int col, const f32x4 &v0, const f32x4 &v1) {
-    store_act(t, rowp, col, v0, v1);
-}
-// one element
-__device__ __forceinline__ void store_act1(bf16 *, char *rowp, int col, float v) { *(bf16 *)(rowp + col * 2) = (bf16)v; }
-__device__ __forceinline__ void store_act1(float *, char *rowp, int col, float v) { *(float *)(rowp + col * 4) = v; }
-__device__ __forceinline__ void store_act1(sp32 *, char *rowp, int col, float v) {
-    bf16 hi, lo;
-    split1(v, hi, lo);
-    *(bf16 *)(rowp + sp_off(col)) = hi;
-    *(bf16 *)(rowp + sp_off(col) + 64) = lo;
-}
-
-// ------------------------------------------------------------------------------------------
-// nn.Linear epilogues
-// ------------------------------------------------------------------------------------------
-// out = epilogue(acc) with the bias already in the accumulator (gemm_mainloop).
-//   MODE 0: fp32 out            MODE 1: fp32 out = resid + acc (resid may alias out)
-//   MODE 2: OE out = gelu(acc)  MODE 3: OE out = acc          (OE = operand type of the next GEMM)
-// Every lane moves 16 B per chunk. The residual of ALL of a lane's chunks is requested in one burst
-// before the first use (one exposed L2 round trip instead of one per unrolled group).
-template <int MODE, class OE>
-struct EpiLinear {
-    const float *bias;
-    const float *resid;
-    void *out;
-    int M, N;
-    int64_t ldo;
-    int wt = 0;  // activation outputs with write-through (sc1) stores
-    template <class Cfg>
-    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
-        constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
-        constexpr bool ACT_OUT = (MODE == 2 || MODE == 3);
-        constexpr int W = ACT_OUT ? Elem<OE>::EPW : 4;  // columns per lane
-        constexpr int CPR = BN / W;                            // chunks per row
-        constexpr int TOTAL = BM * CPR, ITERS = (TOTAL + NT - 1) / NT;
-        f32x4 rs[MODE == 1 ? ITERS : 1];
-        if (MODE == 1) {
-#pragma unroll
-            for (int i = 0; i < ITERS; ++i) {
-                const int q = min((int)threadIdx.x + i * NT, TOTAL - 1), row = q / CPR, col = (q - row * CPR) * W;
-                rs[i] = *(const f32x4 *)(resid + (int64_t)min(m0 + row, M - 1) * ldo + min(n0 + col, N - W));
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < ITERS; ++i) {
-            const int q = threadIdx.x + i * NT, row = q / CPR, col = (q - row * CPR) * W;
-            const int m = m0 + row, n = n0 + col;
-            if ((TOTAL % NT != 0 && q >= TOTAL) || m >= M || n >= N) continue;
-            const int64_t o = (int64_t)m * ldo + n;
-            f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
-            if (!ACT_OUT) {
-                if (MODE == 1) v0 += rs[i];
-                *(f32x4 *)((float *)out + o) = v0;
-            } else {
-                f32x4 v1 = v0;
-                if (W == 8) v1 = *(const f32x4 *)(C + row * BN + col + 4);
-                if (MODE == 2) {
-#pragma unroll
-                    for (int e = 0; e < 4; e += 2) {
-                        const f32x2 a = gelu_erf2(f32x2{v0[e], v0[e + 1]});
-                        v0[e] = a[0];
-                        v0[e + 1] = a[1];
-                        if (W == 8) {
-                            const f32x2 b = gelu_erf2(f32x2{v1[e], v1[e + 1]});
-                            v1[e] = b[0];
-                            v1[e + 1] = b[1];
-                        }
-                    }
-                }
-                if (wt)
-                    store_act_wt((OE *)nullptr, (char *)out + (int64_t)m * ldo * (int)sizeof(OE), n, v0, v1);
-                else
-                    store_act((OE *)nullptr, (char *)out + (int64_t)m * ldo * (int)sizeof(OE), n, v0, v1);
-            }
-        }
-    }
-};
-
-template <class Cfg, class E, bool SWAP, int KSTEPS, class ALoad, class Epi>
-static hipError_t launch_gemm_ks(const ALoad &al, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
-                                 hipStream_t s) {
-    auto kern = gemm_kernel<Cfg, E, SWAP, KSTEPS, ALoad, Epi>;
-    static unsigned long long optin = 0;
-    if (hipError_t e = ensure_lds_optin((const void *)kern, Cfg::LDS_BYTES, optin); e != hipSuccess) return e;
-    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
-    kern<<<dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, s>>>(al, w, ldw, M, N, K, epi);
-    return hipGetLastError();
-}
-
-// The K extents of ViT-S/B (D and 4D, and the patch embedding) get a compile-time step count, which
-// unlocks the two-step prefetch of gemm_mainloop; any other K runs the generic one-step pipeline.
-template <class Cfg, class E, bool SWAP, class ALoad, class Epi>
-static hipError_t launch_gemm(const ALoad &al, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
-                              hipStream_t s) {
-    if (K % Elem<E>::KROW) return hipErrorInvalidValue;
-    switch (K / Elem<E>::KROW) {
-        case 2: return launch_gemm_ks<Cfg, E, SWAP, 2>(al, w, ldw, M, N, K, epi, s);  // Swin stage 0 (K = 96 padded)
-        case 3: return launch_gemm_ks<Cfg, E, SWAP, 3>(al, w, ldw, M, N, K, epi, s);  // Swin stage 1 (K = 192 bf16, 96 fp32)
-        case 4: return launch_gemm_ks<Cfg, E, SWAP, 4>(al, w, ldw, M, N, K, epi, s);
-        case 6: return launch_gemm_ks<Cfg, E, SWAP, 6>(al, w, ldw, M, N, K, epi, s);
-        case 12: return launch_gemm_ks<Cfg, E, SWAP, 12>(al, w, ldw, M, N, K, epi, s);
-        case 24: return launch_gemm_ks<Cfg, E, SWAP, 24>(al, w, ldw, M, N, K, epi, s);
-        case 48: return launch_gemm_ks<Cfg, E, SWAP, 48>(al, w, ldw, M, N, K, epi, s);
-        case 96: return launch_gemm_ks<Cfg, E, SWAP, 96>(al, w, ldw, M, N, K, epi, s);
-        default: break;
-    }
-    return launch_gemm_ks<Cfg, E, SWAP, 0>(al, w, ldw, M, N, K, epi, s);
-}
-
-// ---- LDS-DMA staged variants (gemm_mainloop_dma) ----
-template <class Cfg, class E, int KSTEPS, int NSTAGE, class Epi>
-static hipError_t launch_gemm_dma_ks(const E *a, int64_t lda, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
-                                     hipStream_t s) {
-    constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
-    static_assert(LDS <= 160 * 1024, "LDS ring exceeds the CU");
-    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
-    auto kern = gemm_dma_kernel<Cfg, E, false, KSTEPS, NSTAGE, Epi>;
-    static unsigned long long optin = 0;
-    if (hipError_t e = ensure_lds_optin((const void *)kern, LDS, optin); e != hipSuccess) return e;
-    kern<<<dim3(tiles), dim3(Cfg::NT), LDS, s>>>(a, lda, w, ldw, M, N, K, epi);
-    return hipGetLastError();
-}
-
-template <class Cfg, class E, int NSTAGE, class Epi>
-static hipError_t launch_gemm_dma(const E *a, int64_t lda, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
-                                  hipStream_t s) {
-    if (K % Elem<E>::KROW) return hipErrorInvalidValue;
-    switch (K / Elem<E>::KROW) {
-        case 6: return launch_gemm_dma_ks<Cfg, E, 6, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
-        case 12: return launch_gemm_dma_ks<Cfg, E, 12, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
-        case 24: return launch_gemm_dma_ks<Cfg, E, 24, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
-        case 48: return launch_gemm_dma_ks<Cfg, E, 48, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
-        default: break;
-    }
-    return launch_gemm_dma_ks<Cfg, E, 0, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
-}
-
-typedef GemmCfg<256, 128, 4, 2> Cfg256x128;
-typedef GemmCfg<128, 256, 2, 4> Cfg128x256;
-
-template <int MODE, class E>
-static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, const float *resid, void *out, int M,
-                                     int N, int K, hipStream_t s) {
-    RowLoader<E> al{a, K};
-    EpiLinear<MODE, E> epi{bias, resid, out, M, N, N};
-    epi.wt = ocm_wt_mask() & 1;
-    if constexpr (Elem<E>::MODE == 2) {
-        switch (g_ocm_knobs[0]) {  // development: force a variant (tools/microbench_x3.py)
-            case -1: goto reg_staged;
-            case 1: if (N % 256 == 0) return launch_gemm_dma<Cfg256x256, E, 2>(a, K, w, K, M, N, K, epi, s); break;
-            case 4: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s); break;
-            case 6: if (N % 128 == 0) return launch_gemm_dma<Cfg256x128, E, 2>(a, K, w, K, M, N, K, epi, s); break;
-            case 7: if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 2>(a, K, w, K, M, N, K, epi, s); break;
-            case 8: if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 3>(a, K, w, K, M, N, K, epi, s); break;
-            case 9: if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 4>(a, K, w, K, M, N, K, epi, s); break;
-            case 10: if (N % 64 == 0) return launch_gemm_dma<Cfg64x64, E, 4>(a, K, w, K, M, N, K, epi, s); break;
-            default: break;
-        }
-        // Split-bf16 operands, >= 512 tiles of 128x128 (fc1): LDS-DMA staging, two workgroups per CU. Inside the forward
-        // (ViT-S/16, B = 64, same box, alternating runs) fc1 62 -> 57 us; the 64x128 shapes (proj, fc2) and the qkv
-        // projection measure the same either way (their stand-alone gains of 10 % do not survive cold operands), so
-        // they stay on the register-staged loop.
-        // Few rows (the reference's one-tile-per-call loops, M = 197 .. 785): everything is L2-resident and a launch is a
-        // handful of workgroups, so the LDS-DMA loop's shorter prologue shows (stand-alone, M = 197: fc1 9.4 -> 7.9 us,
-        // fc2 23.1 -> 16.7 us on 64x64 tiles with a 4-deep ring, proj 8.3 -> 7.6 us)
-        if (M <= 1024 && g_ocm_knobs[0] == 0) {
-            if (K >= 1024 && N % 64 == 0) return launch_gemm_dma<Cfg64x64, E, 4>(a, K, w, K, M, N, K, epi, s);
-            if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 2>(a, K, w, K, M, N, K, epi, s);
-        }
-        if (big_tiles_pay(M, N, K))  // ViT-B at 384^2: 256x256 tiles, one 8-wave workgroup per CU (fc1 1020 -> 944 us)
-            return launch_gemm_dma<Cfg256x256, E, 2>(a, K, w, K, M, N, K, epi, s);
-        if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512)
-            return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
-    }
-    if constexpr (Elem<E>::MODE == 0) {  // development A/B: the LDS-DMA loop on single-bf16 operands (knob 0 = 4 / 7)
-        if (g_ocm_knobs[0] == 4 && N % 128 == 0) return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
-        if (g_ocm_knobs[0] == 7 && N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 2>(a, K, w, K, M, N, K, epi, s);
-    }
-reg_staged:
-    if constexpr (Elem<E>::MODE == 0)
-        if (big_tiles_pay(M, N, K)) return launch_gemm<Cfg256x256, E, false>(al, w, K, M, N, K, epi, s);
-    // Tile choice: fill >= 2 workgroups per CU (256 CUs) when the problem allows it.
-    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (N % 128 == 0 && t128 >= 512) return launch_gemm<Cfg128x128, E, false>(al, w, K, M, N, K, epi, s);
-    if (N % 128 == 0 && M > 64) return launch_gemm<Cfg64x128, E, false>(al, w, K, M, N, K, epi, s);
-    return launch_gemm<Cfg64x64, E, false>(al, w, K, M, N, K, epi, s);
-}
-
-template <class E>
-static hipError_t launch_linear_e(const E *a, const E *w, const float *bias, const float *resid, void *out, int M, int N,
-                                  int K, int epilogue, hipStream_t s) {
-    switch (epilogue) {
-        case 0: return launch_linear_mode<0, E>(a, w, bias, resid, out, M, N, K, s);
-        case 1: return launch_linear_mode<1, E>(a, w, bias, resid, out, M, N, K, s);
-        case 2: return launch_linear_mode<2, E>(a, w, bias, resid, out, M, N, K, s);
-        case 3: return launch_linear_mode<3, E>(a, w, bias, resid, out, M, N, K, s);
-    }
-    return hipErrorInvalidValue;
-}
-
-// nn.Linear with explicit row strides (Swin: activations padded to the GEMM's K step, N not a multiple of the
-// tile). N tails are handled by the loaders' row clamps and the epilogue's column guards.
-template <int MODE, class E>
-static hipError_t launch_linear_ld_mode(const E *a, int64_t lda, const E *w, const float *bias, const float *resid,
-                                        void *out, int64_t ldo, int M, int N, int K, hipStream_t s) {
-    RowLoader<E> al{a, lda};
-    EpiLinear<MODE, E> epi{bias, resid, out, M, N, ldo};
-    if (M >= 2048 && N > 64) return launch_gemm<Cfg128x128, E, false>(al, w, K, M, N, K, epi, s);
-    if (M > 64 && N > 64) return launch_gemm<Cfg64x128, E, false>(al, w, K, M, N, K, epi, s);
-    return launch_gemm<Cfg64x64, E, false>(al, w, K, M, N, K, epi, s);
-}
-
-template <class E>
-static hipError_t launch_linear_ld_e(const E *a, int64_t lda, const E *w, const float *bias, const float *resid, void *out,
-                                     int64_t ldo, int M, int N, int K, int epilogue, hipStream_t s) {
-    switch (epilogue) {
-        case 0: return launch_linear_ld_mode<0, E>(a, lda, w, bias, resid, out, ldo, M, N, K, s);
-        case 1: return launch_linear_ld_mode<1, E>(a, lda, w, bias, resid, out, ldo, M, N, K, s);
-        case 2: return launch_linear_ld_mode<2, E>(a, lda, w, bias, resid, out, ldo, M, N, K, s);
-        case 3: return launch_linear_ld_mode<3, E>(a, lda, w, bias, resid, out, ldo, M, N, K, s);
-    }
-    return hipErrorInvalidValue;
-}
+// context stores get slower, 32 -> 39 us). Development knob 1: 0 = shipped mask, -1 = none, any other value = that mask.
+int ocm_wt_mask() { return OCM_KNOB(1) == 0 ? 35 : OCM_KNOB(1) < 0 ? 0 : OCM_KNOB(1); }
 
 hipError_t launch_linear_ld(int prec, const void *a, int64_t lda, const void *w, const float *bias, const float *resid,
                             void *out, int64_t ldo, int M, int N, int K, int epilogue, hipStream_t s) {
@@ -321,135 +48,8 @@ hipError_t launch_linear(int prec, const void *a, const void *w, const float *bi
     return launch_linear_e<bf16>((const bf16 *)a, (const bf16 *)w, bias, resid, out, M, N, K, epilogue, s);
 }
 
-// ------------------------------------------------------------------------------------------
-// proj / fc2 + residual + the LayerNorm that follows (Block.forward :110-111 then :107 / :111 of the next use)
-// ------------------------------------------------------------------------------------------
-// A workgroup owns FULL rows (tile 64 x D), so after x = resid + acc its epilogue can normalise the rows it has just
-// produced and hand the next GEMM its operand directly: one launch and one read + write of the residual stream less
-// per LayerNorm (23 -> 1 LayerNorm launches per ViT-S forward). Statistics are the two-pass fp32 form of
-// layernorm_v4_kernel (half a wavefront per row, the row in registers), on exactly the fp32 values written to x.
-template <class OE, int D_>
-struct EpiResidLN {
-    const float *bias;
-    const float *resid;
-    float *x;           // [M][D] fp32 residual stream out (may alias resid)
-    const float *gamma, *beta;
-    void *xn;           // [M][D] OE: LayerNorm(x) for the next GEMM
-    int M;
-    float eps;
-    int wt = 0;         // bit 0: xn with write-through stores
-    template <class Cfg>
-    __device__ __forceinline__ void run(const float *C, int m0, int) const {
-        constexpr int BM = Cfg::BM, NT = Cfg::NT, NV = D_ / 128;
-        static_assert(Cfg::BN == D_ && D_ % 128 == 0, "full rows, float4 lanes");
-        const int sub = threadIdx.x & 31, half = threadIdx.x >> 5;  // half-wavefront per row
-        constexpr int RPP = NT / 32;                                   // rows per pass
-        f32x4 g[NV], b[NV];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            g[i] = *(const f32x4 *)(gamma + sub * 4 + i * 128);
-            b[i] = *(const f32x4 *)(beta + sub * 4 + i * 128);
-        }
-#pragma unroll 2
-        for (int r0 = 0; r0 < BM; r0 += RPP) {
-            const int row = r0 + half, m = m0 + row;
-            if (m >= M) continue;  // no barriers below
-            f32x4 v[NV];
-#pragma unroll
-            for (int i = 0; i < NV; ++i) v[i] = *(const f32x4 *)(resid + (int64_t)m * D_ + sub * 4 + i * 128);
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                v[i] += *(const f32x4 *)(C + row * D_ + sub * 4 + i * 128);
-                if (wt & 2)
-                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(x + (int64_t)m * D_ + sub * 4 + i * 128), "v"(v[i]) : "memory");
-                else
-                    *(f32x4 *)(x + (int64_t)m * D_ + sub * 4 + i * 128) = v[i];
-                s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-            }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            const float mean = s * (1.0f / D_);
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = v[i][e] - mean;
-                    q = fmaf(d, d, q);
-                }
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-            const float rstd = 1.0f / sqrtf(q * (1.0f / D_) + eps);
-            char *rowp = (char *)xn + (int64_t)m * D_ * (int)sizeof(OE);
-#pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int c = sub * 4 + i * 128;
-                f32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[i][e] + b[i][e];
-                if constexpr (Elem<OE>::MODE == 0) {
-                    bf16x4 ob;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) ob[e] = (bf16)o[e];
-                    *(bf16x4 *)(rowp + c * 2) = ob;
-                } else if constexpr (Elem<OE>::MODE == 1) {
-                    *(f32x4 *)(rowp + c * 4) = o;
-                } else {
-                    bf16x4 hi, lo;
-                    split4(o, hi, lo);
-                    if (wt & 1) {
-                        const f32x2 dh = __builtin_bit_cast(f32x2, hi), dl = __builtin_bit_cast(f32x2, lo);
-                        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(rowp + sp_off(c)), "v"(dh) : "memory");
-                        asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_nop 1" ::"v"(rowp + sp_off(c) + 64), "v"(dl) : "memory");
-                    } else {
-                        *(bf16x4 *)(rowp + sp_off(c)) = hi;
-                        *(bf16x4 *)(rowp + sp_off(c) + 64) = lo;
-                    }
-                }
-            }
-        }
-    }
-};
-
-template <class E, int D_>
-static hipError_t launch_resid_ln_d(const E *a, const E *w, const float *bias, const float *resid, float *x,
-                                    const float *gamma, const float *beta, void *xn, int M, int K, float eps,
-                                    hipStream_t s) {
-    typedef GemmCfg<64, D_, 2, 4> Cfg;  // 8 waves, wave tile 32 x D/4
-    EpiResidLN<E, D_> epi{bias, resid, x, gamma, beta, xn, M, eps};
-    epi.wt = ((ocm_wt_mask() >> 2) & 1) | ((ocm_wt_mask() >> 4) & 2);  // mask 4: xn, mask 32: x
-    if constexpr (Elem<E>::MODE == 2) {
-        // One 8-wave workgroup per CU: the two-step register prefetch hides more latency than a two-stage LDS-DMA ring
-        // (fc2 + LayerNorm at ViT-S/16, B = 64: 72 us against 89 us), and a third stage does not fit next to the
-        // 96 KiB epilogue image. Knob 4 = 2 forces the DMA loop (development A/B).
-        if (g_ocm_knobs[4] == 2) {
-            if (K % Elem<E>::KROW) return hipErrorInvalidValue;
-            switch (K / Elem<E>::KROW) {
-                case 12: return launch_gemm_dma_ks<Cfg, E, 12, 2>(a, K, w, K, M, D_, K, epi, s);
-                case 48: return launch_gemm_dma_ks<Cfg, E, 48, 2>(a, K, w, K, M, D_, K, epi, s);
-                default: return launch_gemm_dma_ks<Cfg, E, 0, 2>(a, K, w, K, M, D_, K, epi, s);
-            }
-        }
-    }
-    RowLoader<E> al{a, K};
-    return launch_gemm<Cfg, E, false>(al, w, K, M, D_, K, epi, s);
-}
-
-template <class E>
-static hipError_t launch_resid_ln_e(const E *a, const E *w, const float *bias, const float *resid, float *x,
-                                    const float *gamma, const float *beta, void *xn, int M, int D, int K, float eps,
-                                    hipStream_t s) {
-    switch (D) {
-        case 128: return launch_resid_ln_d<E, 128>(a, w, bias, resid, x, gamma, beta, xn, M, K, eps, s);
-        case 256: return launch_resid_ln_d<E, 256>(a, w, bias, resid, x, gamma, beta, xn, M, K, eps, s);
-        case 384: return launch_resid_ln_d<E, 384>(a, w, bias, resid, x, gamma, beta, xn, M, K, eps, s);
-        case 512: return launch_resid_ln_d<E, 512>(a, w, bias, resid, x, gamma, beta, xn, M, K, eps, s);
-        default: return hipErrorInvalidValue;
-    }
-}
-
-bool linear_resid_ln_supported(int D) { return D == 128 || D == 256 || D == 384 || D == 512; }
+// D = 512 is not offered: its split-bf16 instantiation needs more than 256 registers per lane (scratch spills)
+bool linear_resid_ln_supported(int D) { return D == 128 || D == 256 || D == 384; }
 
 // x = resid + A W^T + bias;  xn = LayerNorm(x; gamma, beta, eps) in the activation type of `prec`
 hipError_t launch_linear_resid_ln(int prec, const void *a, const void *w, const float *bias, const float *resid, float *x,
@@ -460,226 +60,6 @@ hipError_t launch_linear_resid_ln(int prec, const void *a, const void *w, const 
     if (prec)
         return launch_resid_ln_e<float>((const float *)a, (const float *)w, bias, resid, x, gamma, beta, xn, M, D, K, eps, s);
     return launch_resid_ln_e<bf16>((const bf16 *)a, (const bf16 *)w, bias, resid, x, gamma, beta, xn, M, D, K, eps, s);
-}
-
-// ------------------------------------------------------------------------------------------
-// qkv projection -> head-major q, k and key-contiguous V^T
-// ------------------------------------------------------------------------------------------
-// Wqkv rows are ordered q(h0..hH-1), k(...), v(...), each head's 64 rows contiguous (:80).
-// Column tiles inside [0, 2D) produce q/k rows  dst[(b*H + head)][t][d]          (d contiguous);
-// column tiles inside [2D, 3D) run the main loop with the MFMA operands swapped, so the
-// accumulator is transposed (lane = token) and V is written as V^T  vt[(b*H + head)][d][t]
-// with the token index contiguous — the layout the P·V MFMA consumes — at full store width.
-template <class E>
-struct EpiQK {
-    const float *bias;
-    E *q, *k;      // head-major operand copies (head_dim 64 only), or nullptr
-    float *qkv32;  // optional (3,B,H,N,hd) fp32, or nullptr
-    int M, ntok, npad, H, D, B, hd;
-    int wt = 0;  // write-through stores for q / k
-    // C is [BM][BN] (rows = tokens). One lane moves 8 consecutive head-dim columns of one token. A lane keeps its
-    // column chunk for the whole tile and walks the rows in constant steps, so which / head / d are computed once
-    // and (image b, token t) advance incrementally: no integer division per chunk.
-    template <class Cfg>
-    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
-        constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, CPR = BN / 8;
-        static_assert(NT % CPR == 0 && BM % (NT / CPR) == 0, "a lane keeps one column chunk");
-        constexpr int RSTEP = NT / CPR, ITERS = BM / RSTEP;
-        const int col = (threadIdx.x % CPR) * 8, row0 = threadIdx.x / CPR;
-        const int n = n0 + col;
-        const int which = n / D, rem = n - which * D;
-        const int head = hd == 64 ? rem >> 6 : rem / hd, d = rem - head * hd;
-        int m = m0 + row0;
-        int b = m / ntok, t = m - b * ntok;
-        E *base = which ? k : q;
-#pragma unroll 4
-        for (int i = 0; i < ITERS; ++i) {
-            if (m >= M) break;
-            const int row = row0 + i * RSTEP;
-            const f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
-            const f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4);
-            if (base) {
-                char *rowp = (char *)base + ((int64_t)(b * H + head) * npad + t) * 64 * (int)sizeof(E);
-                if (Elem<E>::EPW == 8) {
-                    if (wt)
-                        store_act_wt((E *)nullptr, rowp, d, v0, v1);
-                    else
-                        store_act((E *)nullptr, rowp, d, v0, v1);
-                } else {
-                    store_act((E *)nullptr, rowp, d, v0, v0);
-                    store_act((E *)nullptr, rowp, d + 4, v1, v1);
-                }
-            }
-            if (qkv32) {
-                float *o = qkv32 + ((((int64_t)which * B + b) * H + head) * ntok + t) * hd + d;
-                *(f32x4 *)o = v0;
-                *(f32x4 *)(o + 4) = v1;
-            }
-            m += RSTEP;
-            t += RSTEP;
-            while (t >= ntok) {
-                t -= ntok;
-                ++b;
-            }
-        }
-    }
-};
-
-template <class E>
-struct EpiVt {
-    const float *bias;
-    E *vt;  // key-contiguous V^T (head_dim 64 only); a null vt with a non-null qkv32 still computes the V third
-    float *qkv32;
-    int M, ntok, npad, H, D, B, hd;
-    bool want_v;  // compute the V third at all
-    // C is the TRANSPOSED tile [BN][BM] (rows = features n, columns = tokens m). Consecutive lanes
-    // take consecutive tokens of one feature row, so each store instruction writes contiguous runs
-    // of V^T (vt[(b*H+head)][d][t], t contiguous).
-    template <class Cfg>
-    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
-        constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
-        constexpr int RS = NT >= BM ? NT / BM : 1;  // feature rows handled per sweep
-        static_assert(NT >= BM, "one lane per token column");
-        if (threadIdx.x >= RS * BM) return;
-        const int col = threadIdx.x % BM, m = m0 + col;
-        if (m >= M) return;
-        const int b = m / ntok, t = m - b * ntok;
-        const int rem0 = n0 - 2 * D;
-#pragma unroll 4
-        for (int row = threadIdx.x / BM; row < BN; row += RS) {
-            const int rem = rem0 + row;
-            const int head = hd == 64 ? rem >> 6 : rem / hd, d = rem - head * hd;  // no integer division on the hot path
-            const float v = C[row * BM + col];
-            if (vt) store_act1((E *)nullptr, (char *)vt + ((int64_t)(b * H + head) * 64 + d) * npad * (int)sizeof(E), t, v);
-            if (qkv32) qkv32[((((int64_t)2 * B + b) * H + head) * ntok + t) * hd + d] = v;
-        }
-    }
-};
-
-template <class Cfg, class E, int KSTEPS>
-__global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader<E> al, const E *__restrict__ W, int M, int D,
-                                                      EpiQK<E> eqk, EpiVt<E> ev) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N = 3 * D, K = D;
-    // D % BN == 0 is checked by the launcher; without a V^T destination (a block that stops after its
-    // attention probabilities) the V third of the projection is not computed at all
-    const int tiles_n = (ev.want_v ? N : 2 * D) / Cfg::BN;
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = id / tiles_n, tn = id - tm * tiles_n;
-    const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
-    f32x16 acc[Cfg::TM][Cfg::TN];
-    if (n0 < 2 * D) {  // workgroup-uniform
-        gemm_mainloop<Cfg, E, false, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
-        run_epilogue<Cfg, false>(acc, smem, eqk, m0, n0);
-    } else {
-        gemm_mainloop<Cfg, E, true, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
-        run_epilogue<Cfg, true>(acc, smem, ev, m0, n0);
-    }
-}
-
-// LDS-DMA staged variant (gemm_mainloop_dma); dynamic LDS = NSTAGE * (BM + BN) * 128
-template <class Cfg, class E, int KSTEPS, int NSTAGE>
-__global__ __launch_bounds__(Cfg::NT) void qkv_dma_kernel(const E *__restrict__ A, const E *__restrict__ W, int M, int D,
-                                                          EpiQK<E> eqk, EpiVt<E> ev) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int N = 3 * D, K = D;
-    const int tiles_n = (ev.want_v ? N : 2 * D) / Cfg::BN;
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = id / tiles_n, tn = id - tm * tiles_n;
-    const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
-    f32x16 acc[Cfg::TM][Cfg::TN];
-    if (n0 < 2 * D) {  // workgroup-uniform
-        gemm_mainloop_dma<Cfg, E, false, KSTEPS, NSTAGE>(A, K, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
-        run_epilogue<Cfg, false>(acc, smem, eqk, m0, n0);
-    } else {
-        gemm_mainloop_dma<Cfg, E, true, KSTEPS, NSTAGE>(A, K, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
-        run_epilogue<Cfg, true>(acc, smem, ev, m0, n0);
-    }
-}
-
-template <class Cfg, class E, int KSTEPS, int NSTAGE>
-static hipError_t launch_qkv_dma_ks(const E *a, const E *w, int M, int D, const EpiQK<E> &eqk, const EpiVt<E> &ev,
-                                    hipStream_t s) {
-    auto kern = qkv_dma_kernel<Cfg, E, KSTEPS, NSTAGE>;
-    constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
-    static unsigned long long optin = 0;
-    if (hipError_t e = ensure_lds_optin((const void *)kern, LDS, optin); e != hipSuccess) return e;
-    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((ev.want_v ? 3 : 2) * D / Cfg::BN);
-    kern<<<dim3(tiles), dim3(Cfg::NT), LDS, s>>>(a, w, M, D, eqk, ev);
-    return hipGetLastError();
-}
-
-template <class Cfg, class E, int NSTAGE>
-static hipError_t launch_qkv_dma(const E *a, const E *w, int M, int D, const EpiQK<E> &eqk, const EpiVt<E> &ev,
-                                 hipStream_t s) {
-    switch (D / Elem<E>::KROW) {
-        case 12: return launch_qkv_dma_ks<Cfg, E, 12, NSTAGE>(a, w, M, D, eqk, ev, s);
-        case 24: return launch_qkv_dma_ks<Cfg, E, 24, NSTAGE>(a, w, M, D, eqk, ev, s);
-        default: break;
-    }
-    return launch_qkv_dma_ks<Cfg, E, 0, NSTAGE>(a, w, M, D, eqk, ev, s);
-}
-
-template <class Cfg, class E, int KSTEPS>
-static hipError_t launch_qkv_ks(const RowLoader<E> &al, const E *w, int M, int D, const EpiQK<E> &eqk,
-                                const EpiVt<E> &ev, hipStream_t s) {
-    auto kern = qkv_kernel<Cfg, E, KSTEPS>;
-    static unsigned long long optin = 0;
-    if (hipError_t e = ensure_lds_optin((const void *)kern, Cfg::LDS_BYTES, optin); e != hipSuccess) return e;
-    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((ev.want_v ? 3 : 2) * D / Cfg::BN);
-    kern<<<dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, s>>>(al, w, M, D, eqk, ev);
-    return hipGetLastError();
-}
-
-template <class Cfg, class E>
-static hipError_t launch_qkv_cfg(const RowLoader<E> &al, const E *w, int M, int D, const EpiQK<E> &eqk,
-                                 const EpiVt<E> &ev, hipStream_t s) {
-    switch (D / Elem<E>::KROW) {
-        case 6: return launch_qkv_ks<Cfg, E, 6>(al, w, M, D, eqk, ev, s);
-        case 12: return launch_qkv_ks<Cfg, E, 12>(al, w, M, D, eqk, ev, s);
-        case 24: return launch_qkv_ks<Cfg, E, 24>(al, w, M, D, eqk, ev, s);
-        default: break;
-    }
-    return launch_qkv_ks<Cfg, E, 0>(al, w, M, D, eqk, ev, s);
-}
-
-template <class E>
-static hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E *vt, float *qkv_f32, int batch,
-                               int n_tokens, int n_pad, int heads, int head_dim, bool want_v, hipStream_t s) {
-    const int D = heads * head_dim, M = batch * n_tokens;
-    if (head_dim != 64 && (q || k || vt)) return hipErrorInvalidValue;  // operand copies exist for 64-channel heads only
-    if (head_dim % 8) return hipErrorInvalidValue;                      // a lane's 8 columns stay inside one head
-    RowLoader<E> al{a, D};
-    EpiQK<E> eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch, head_dim};
-    eqk.wt = (ocm_wt_mask() >> 1) & 1;
-    EpiVt<E> ev{bias, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch, head_dim, want_v};
-    if constexpr (Elem<E>::MODE == 0)
-        if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_cfg<Cfg256x256, E>(al, w, M, D, eqk, ev, s);
-    const long t128 = (long)((M + 127) / 128) * (3 * D / 128);
-    if constexpr (Elem<E>::MODE == 2) {
-        if (D % 128 == 0 && M > 64) {
-            switch (g_ocm_knobs[3]) {  // development: force a variant (-1: the register-staged kernels below)
-                case 1: return launch_qkv_dma<Cfg128x128, E, 2>(a, w, M, D, eqk, ev, s);
-                case 2: return launch_qkv_dma<Cfg128x128q, E, 2>(a, w, M, D, eqk, ev, s);
-                case 3: return launch_qkv_dma<Cfg64x128, E, 2>(a, w, M, D, eqk, ev, s);
-                case 4: if (D % 256 == 0) return launch_qkv_dma<Cfg256x256, E, 2>(a, w, M, D, eqk, ev, s); break;
-                default: break;
-            }
-            if (g_ocm_knobs[3] == 0) {
-                // few rows (one tile per call): the DMA loop's shorter prologue shows (B = 1 forward 1.03 -> 1.01 ms)
-                if (M <= 1024) return launch_qkv_dma<Cfg64x128, E, 2>(a, w, M, D, eqk, ev, s);
-                // ViT-B sizes: 256 x 256 tiles halve the bytes through L2 (384^2 B = 128: 755 -> 715 us per launch)
-                if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_dma<Cfg256x256, E, 2>(a, w, M, D, eqk, ev, s);
-                // the 8-wave 128 x 128 tile on the LDS-DMA loop (ViT-S/16 B = 64: 46.6 -> 41.8 us per launch, +2 % end
-                // to end; ViT-B/16 384^2 B = 128: 805 -> 759 us; alternating runs on one box). The 4-wave form of the
-                // same tile (variant 1) measures like the register-staged kernel.
-                if (t128 >= 512) return launch_qkv_dma<Cfg128x128q, E, 2>(a, w, M, D, eqk, ev, s);
-            }
-        }
-    }
-    if (D % 128 == 0 && t128 >= 512) return launch_qkv_cfg<Cfg128x128q, E>(al, w, M, D, eqk, ev, s);
-    if (D % 128 == 0) return launch_qkv_cfg<Cfg64x128, E>(al, w, M, D, eqk, ev, s);
-    return launch_qkv_cfg<Cfg64x64, E>(al, w, M, D, eqk, ev, s);
 }
 
 hipError_t launch_qkv(int prec, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
@@ -695,102 +75,6 @@ hipError_t launch_qkv(int prec, const void *a, const void *w, const float *bias,
                               n_tokens, n_pad, heads, head_dim, want_v, s);
 }
 
-// ------------------------------------------------------------------------------------------
-// patch embedding: im2col-free gather from fp32 planes + GEMM + bias + pos-embed
-// ------------------------------------------------------------------------------------------
-// Row m = b*P + py*wp + px is the p x p patch at (py, px) of tile b (row-major flatten, :131);
-// column k = c*p*p + dy*p + dx indexes conv weight (D, C, p, p) flattened (:127). A 16-B LDS
-// chunk is 8 (bf16) or 4 (fp32) consecutive dx of one (c, dy): float4 loads from one image row,
-// converted to bf16 on the way into LDS in the bf16 path. Consecutive threads walk consecutive
-// chunks of a row, so a wave reads whole row segments of neighbouring patches (coalesced along x).
-template <class E>
-struct PatchLoader {
-    const float *image;
-    int64_t sb, sc, sy;
-    const int32_t *origins;
-    int P, wp, p, pp;
-    typedef const float *Handle;
-    struct Raw {
-        f32x4 lo, hi;
-    };
-    __device__ __forceinline__ Handle row(int m) const {
-        const int b = m / P, pi = m - b * P;
-        const int py = pi / wp, px = pi - py * wp;
-        int y0 = 0, x0 = 0;
-        if (origins) {
-            y0 = origins[2 * b];
-            x0 = origins[2 * b + 1];
-        }
-        return image + (int64_t)b * sb + (int64_t)(y0 + py * p) * sy + x0 + px * p;
-    }
-    // chunk cc of K step t: bf16 -> k = 64t + 8cc .. +7; fp32 -> k = 32t + 4cc .. +3; split pairs -> the hi (cc < 4)
-    // or lo (cc >= 4) halves of k = 32t + 8(cc & 3) .. +7
-    __device__ __forceinline__ Raw load(Handle h, int t, int cc) const {
-        constexpr int MODE = Elem<E>::MODE;
-        const int k = MODE == 0 ? t * 64 + cc * 8 : MODE == 1 ? t * 32 + cc * 4 : t * 32 + (cc & 3) * 8;
-        const int c = k / pp, rem = k - c * pp;
-        const int dy = rem / p, dx = rem - dy * p;
-        const float *ptr = h + (int64_t)c * sc + (int64_t)dy * sy + dx;
-        Raw r;
-        r.lo = *(const f32x4 *)ptr;
-        r.hi = r.lo;
-        if (MODE != 1) r.hi = *(const f32x4 *)(ptr + 4);
-        return r;
-    }
-    __device__ __forceinline__ static typename Elem<E>::Chunk finish(const Raw &r, int cc) {
-        if constexpr (Elem<E>::MODE == 0) {
-            return cvt8(r.lo, r.hi);
-        } else if constexpr (Elem<E>::MODE == 1) {
-            return r.lo;
-        } else {
-            bf16x8 hi, lo;
-            split8(r.lo, r.hi, hi, lo);
-            const bf16x8 sel = cc < 4 ? hi : lo;
-            return __builtin_bit_cast(f32x4, sel);
-        }
-    }
-};
-
-// x[b][1 + pi][n] = acc + pos[1 + pi][n]   (prepare_tokens :200-207, patch rows; bias is in acc)
-// With a SimMIM mask (model.py:28-33) the patch row is first blended with the mask token:
-// acc*(1-w) + mask_token*w, w = mask[b][pi], evaluated in that order in fp32.
-struct EpiPatch {
-    const float *bias, *pos;
-    float *x;
-    int M, P, ntok, D;
-    const float *mask, *mask_tok;
-    template <class Cfg>
-    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
-        constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, CPR = BN / 4;
-#pragma unroll 4
-        for (int q = threadIdx.x; q < BM * CPR; q += NT) {
-            const int row = q / CPR, col = (q - row * CPR) * 4;
-            const int m = m0 + row, n = n0 + col;
-            if (m >= M || n >= D) continue;
-            const int b = m / P, t = m - b * P;
-            f32x4 v = *(const f32x4 *)(C + row * BN + col);
-            if (mask) {
-                const float w = mask[m], omw = 1.0f - w;
-                const f32x4 tk = *(const f32x4 *)(mask_tok + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] * omw + tk[e] * w;  // exact for the 0/1 masks SimMIM draws
-            }
-            v += *(const f32x4 *)(pos + (int64_t)(1 + t) * D + n);
-            *(f32x4 *)(x + ((int64_t)b * ntok + 1 + t) * D + n) = v;
-        }
-    }
-};
-
-template <class E>
-static hipError_t launch_patch_e(const PatchArgs &pa, const E *w, const float *bias, const float *pos, float *x, int dim,
-                                 hipStream_t s) {
-    const int P = pa.hp * pa.wp, M = pa.batch * P, K = pa.chans * pa.p * pa.p;
-    PatchLoader<E> al{pa.image, pa.sb, pa.sc, pa.sy, pa.origins, P, pa.wp, pa.p, pa.p * pa.p};
-    EpiPatch epi{bias, pos, x, M, P, P + 1, dim, pa.mask, pa.mask_tok};
-    if (dim % 128 == 0 && M > 64) return launch_gemm<Cfg64x128, E, false>(al, w, K, M, dim, K, epi, s);
-    return launch_gemm<Cfg64x64, E, false>(al, w, K, M, dim, K, epi, s);
-}
-
 hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, const float *bias, const float *pos,
                               float *x, int dim, hipStream_t s) {
     if (prec == 2) return launch_patch_e<sp32>(pa, (const sp32 *)w, bias, pos, x, dim, s);
@@ -798,24 +82,3 @@ hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, cons
     return launch_patch_e<bf16>(pa, (const bf16 *)w, bias, pos, x, dim, s);
 }
 
-#ifdef OCM_GEMM_STAMPS
-// development only: workgroups per CU the runtime grants a few of the shipped kernels (tools/stamps_x3.py)
-extern "C" int ocm_debug_occupancy(int *out, int n) {
-    int k = 0, v = 0;
-    auto q = [&](const void *f, int threads, size_t lds) {
-        v = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, f, threads, lds);
-        if (k < n) out[k++] = v;
-    };
-    q((const void *)gemm_dma_kernel<Cfg64x128, sp32, false, 48, 2, EpiLinear<1, sp32>, 0>, 256, 2 * 192 * 128);
-    q((const void *)gemm_dma_kernel<Cfg128x128, sp32, false, 12, 2, EpiLinear<2, sp32>, 0>, 256, 2 * 256 * 128);
-    q((const void *)qkv_dma_kernel<Cfg128x128q, sp32, 12, 2>, 512, 2 * 256 * 128);
-    q((const void *)gemm_kernel<GemmCfg<64, 384, 2, 4>, sp32, false, 48, RowLoader<sp32>, EpiResidLN<sp32, 384>>, 512,
-      GemmCfg<64, 384, 2, 4>::LDS_BYTES);
-    return k;
-}
-// development only: copy the cycle stamps of the last GEMM launches to the host (tools/stamps.py)
-extern "C" int ocm_debug_stamps(unsigned long long *host, int n) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * 8);
-}
-#endif

@@ -27,7 +27,7 @@ hipError_t launch_linear(int prec, const void *a, const void *w, const float *bi
                          int N, int K, int epilogue, hipStream_t s);
 // head_dim 64: q / k / vt are the attention kernels' operand copies (vt may be null when V is never read: want_v
 // false skips the V third). Any other head_dim (multiple of 8): q = k = vt = null, qkv_f32 (3,B,H,N,hd) is the output.
-// proj / fc2 + residual fused with the LayerNorm that follows (full-row tiles, D in {128, 256, 384, 512})
+// proj / fc2 + residual fused with the LayerNorm that follows (full-row tiles, D in {128, 256, 384})
 bool linear_resid_ln_supported(int D);
 hipError_t launch_linear_resid_ln(int prec, const void *a, const void *w, const float *bias, const float *resid, float *x,
                                   const float *gamma, const float *beta, void *xn, int M, int D, int K, float eps,

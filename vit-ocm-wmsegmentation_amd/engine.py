@@ -191,6 +191,12 @@ class Engine:
             check(self.lib.ocm_vit_forward(self._h, C.byref(io)))
         return out
 
+    def set_fuse_layernorm(self, mode):
+        """Per-handle dispatch option OCM_OPT_FUSE_LN: "auto" (default: where it is faster), "never", "always" (whenever the
+        embedding width has the full-row GEMM + LayerNorm kernel). All three give bit-identical results."""
+        value = {"auto": 0, "never": 1, "always": 2}[mode]
+        check(self.lib.ocm_vit_set_option(self._h, _lib.OCM_OPT_FUSE_LN, value))
+
     def graph_stats(self):
         """(replays, captures) of the hipGraph path."""
         a, b = C.c_uint64(0), C.c_uint64(0)
