@@ -98,8 +98,12 @@ int ocm_vit_set_param(ocm_vit_t *h, const char *name, const float *dev_src, size
  *   OCM_OPT_FUSE_LN  attn.proj / mlp.fc2 + residual fused with the LayerNorm that follows (one full-row kernel, bit
  *                    identical to the GEMM + LayerNorm pair): 0 = where it is faster (>= 8192 token rows and fewer than
  *                    512 tiles of 128 x 128 in the output), 1 = never, 2 = whenever the embedding width has the kernel
- *                    (ocm_linear_resid_ln_supported). */
-enum { OCM_OPT_FUSE_LN = 0, OCM_OPT_COUNT = 1 };
+ *                    (ocm_linear_resid_ln_supported).
+ *   OCM_OPT_FOLD_LN  (OCM_PREC_BF16X3 engines) LayerNorm folded into the GEMM that consumes it: the residual stream is
+ *                    handed over un-normalised as split pairs with per-row sums, the consumer multiplies by W * gamma
+ *                    and finishes rstd * (acc - mu * c) + d in its epilogue — no LayerNorm launches, no full-row tiles.
+ *                    0 = on (ocm_vit_forward; the block-level entry points keep the LayerNorm kernels), 1 = never. */
+enum { OCM_OPT_FUSE_LN = 0, OCM_OPT_FOLD_LN = 1, OCM_OPT_COUNT = 2 };
 int ocm_vit_set_option(ocm_vit_t *h, int32_t option, int32_t value);
 /* 0 when every parameter has been set, else OCM_ESTATE with the first missing
  * name in ocm_last_error(). */

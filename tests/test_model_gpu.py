@@ -270,6 +270,7 @@ def test_fused_gemm_layernorm_is_bit_identical(dev, lib, name, precision):
     x = case_inputs(case)[0].to(dev)
     eng = model._engine(dev)
     try:
+        eng.set_fold_layernorm(False)  # split-bf16 engines fold the LayerNorm into its consumer by default: not this test's subject
         eng.set_fuse_layernorm("never")
         f0, a0, q0 = model.get_intermediate_feat(x, 2)
         l0 = model.get_last_selfattention(x)
@@ -278,13 +279,47 @@ def test_fused_gemm_layernorm_is_bit_identical(dev, lib, name, precision):
         l1 = model.get_last_selfattention(x)
     finally:
         eng.set_fuse_layernorm("auto")
+        eng.set_fold_layernorm(True)
     with pytest.raises(ValueError):
-        lib.ocm_vit_set_option.errcheck = None
         from vit_ocm_wmsegmentation_amd import _lib as L
         L.check(lib.ocm_vit_set_option(eng._h, 7, 0))  # unknown option
     assert not hasattr(lib, "ocm_debug_knob") or "OCM_VIT_LIB" in __import__("os").environ  # product build: no knobs
     for u, v in zip(f0 + a0 + q0 + [l0], f1 + a1 + q1 + [l1]):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("name", ["tiny_p8", "vits16_peaked"])
+def test_folded_layernorm_matches_layernorm_kernels(dev, name):
+    """Split-bf16 default: every LayerNorm is folded into the GEMM that consumes it (un-normalised split operands + row
+    sums, rstd * (acc - mu c) + d in the epilogue; Block.forward dino/vision_transformer.py:107,111). Against the same
+    engine with LayerNorm kernels: the same arithmetic up to operand rounding (2^-17), and — no atomics in the row sums —
+    the same bits from call to call."""
+    case = CASES[name]
+    model = build_module(case, dev)
+    x = case_inputs(case)[0].to(dev)
+    eng = model._engine(dev)
+    f1, a1, q1 = model.get_intermediate_feat(x, 2)
+    f1b, a1b, q1b = model.get_intermediate_feat(x, 2)
+    for u, v in zip(f1 + a1 + q1, f1b + a1b + q1b):
+        assert torch.equal(u, v)
+    try:
+        eng.set_fold_layernorm(False)
+        f0, a0, q0 = model.get_intermediate_feat(x, 2)
+    finally:
+        eng.set_fold_layernorm(True)
+    tol = 5e-4 if name in STRESS else 1e-6
+    for u, v in zip(a0, a1):
+        assert float((u - v).abs().max()) <= tol
+    for u, v in zip(f0 + q0, f1 + q1):
+        assert _rel(u.cpu(), v.cpu()) < (2e-3 if name in STRESS else 1e-4)
+    # a LayerNorm parameter changed in place is picked up (the folded weights are rebuilt before the next forward)
+    with torch.no_grad():
+        model.blocks[0].norm1.weight.mul_(1.25)
+        model.blocks[1].norm2.bias.add_(0.1)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = O.make_cfg(sd, case["patch"], case_dims(case)[2])
+    ref = O.get_last_selfattention(sd, cfg, x.cpu())
+    assert float((model.get_last_selfattention(x).cpu() - ref).abs().max()) <= ATTN_TOL
 
 
 @pytest.mark.parametrize("size,stride,window", [(200, 32, 96), (160, 32, 128), (130, 32, 96)])

@@ -119,6 +119,11 @@ struct Param {
 
 struct BlockP {
     int ln1_g, ln1_b, qkv_w, qkv_b, proj_w, proj_b, ln2_g, ln2_b, fc1_w, fc1_b, fc2_w, fc2_b;
+    // split-bf16 engines only (LayerNorm folded into its consumer): fp32 copies of the two weight matrices
+    // that follow a LayerNorm, and what is derived from them: W' = W * gamma as split pairs, c = row sums of W',
+    // d = W beta + bias
+    int qkv_w32 = -1, fc1_w32 = -1, qkv_wf = -1, fc1_wf = -1, qkv_c = -1, qkv_d = -1, fc1_c = -1, fc1_d = -1;
+    bool fold_dirty = true;
 };
 
 struct ocm_vit {
@@ -140,6 +145,8 @@ struct ocm_vit {
     bool graph_valid = false;
     uint64_t graph_hits = 0, graph_captures = 0;
     int32_t opt[OCM_OPT_COUNT] = {0};  // ocm_vit_set_option: per-handle dispatch options (0 = automatic)
+    bool can_fold() const { return prec == 2; }  // LayerNorm folding exists for the split-bf16 kernels
+    bool folding() const { return can_fold() && opt[OCM_OPT_FOLD_LN] != 1; }
 
     int add(const std::string &name, ParamKind kind, size_t count, size_t stored_elems) {
         Param pr{name, kind, count, arena_bytes, false};
@@ -196,6 +203,21 @@ extern "C" int ocm_vit_create(const ocm_vit_config *cfg, ocm_vit_t **out) {
         bp.fc1_b = h->add(b + "mlp.fc1.bias", P_F32, m, m);
         bp.fc2_w = h->add(b + "mlp.fc2.weight", P_BF16, d * m, d * m);
         bp.fc2_b = h->add(b + "mlp.fc2.bias", P_F32, d, d);
+        if (h->prec == 2) {  // derived / shadow entries: never set through ocm_vit_set_param by name
+            auto derived = [&](const char *nm, ParamKind kind, size_t elems) {
+                const int idx = h->add(b + nm, kind, elems, elems);
+                h->params[idx].optional = true;
+                return idx;
+            };
+            bp.qkv_w32 = derived("~qkv.w32", P_F32, 3 * d * d);
+            bp.fc1_w32 = derived("~fc1.w32", P_F32, m * d);
+            bp.qkv_wf = derived("~qkv.wf", P_BF16, 3 * d * d);
+            bp.fc1_wf = derived("~fc1.wf", P_BF16, m * d);
+            bp.qkv_c = derived("~qkv.c", P_F32, 3 * d);
+            bp.qkv_d = derived("~qkv.d", P_F32, 3 * d);
+            bp.fc1_c = derived("~fc1.c", P_F32, m);
+            bp.fc1_d = derived("~fc1.d", P_F32, m);
+        }
         h->blk.push_back(bp);
     }
     h->norm_g = h->add("norm.weight", P_F32, d, d);
@@ -260,6 +282,20 @@ extern "C" int ocm_vit_set_param(ocm_vit_t *h, const char *name, const float *de
             }
         }
         pr.set = true;
+        if (h->can_fold() && pr.name.compare(0, 7, "blocks.") == 0) {  // keep the folded-LayerNorm operands in step
+            const size_t dot = pr.name.find('.', 7);
+            const int bi = atoi(pr.name.c_str() + 7);
+            if (dot != std::string::npos && bi >= 0 && bi < h->L) {
+                BlockP &bp = h->blk[bi];
+                const std::string leaf = pr.name.substr(dot + 1);
+                if (leaf == "attn.qkv.weight")
+                    HIP_TRY(hipMemcpyAsync(h->ptr<char>(bp.qkv_w32), dev_src, count * 4, hipMemcpyDeviceToDevice, s));
+                if (leaf == "mlp.fc1.weight")
+                    HIP_TRY(hipMemcpyAsync(h->ptr<char>(bp.fc1_w32), dev_src, count * 4, hipMemcpyDeviceToDevice, s));
+                if (leaf.compare(0, 4, "norm") == 0 || leaf.compare(0, 8, "attn.qkv") == 0 || leaf.compare(0, 7, "mlp.fc1") == 0)
+                    bp.fold_dirty = true;
+            }
+        }
         return OCM_OK;
     }
     return fail(OCM_ENAME, "unknown parameter '%s'", name);
@@ -269,8 +305,24 @@ extern "C" int ocm_vit_set_option(ocm_vit_t *h, int32_t option, int32_t value) {
     if (!h) return fail(OCM_EINVAL, "null handle");
     if (option < 0 || option >= OCM_OPT_COUNT) return fail(OCM_EINVAL, "unknown option %d", option);
     if (option == OCM_OPT_FUSE_LN && (value < 0 || value > 2)) return fail(OCM_EINVAL, "OCM_OPT_FUSE_LN takes 0 (auto), 1 (never) or 2 (always)");
+    if (option == OCM_OPT_FOLD_LN && (value < 0 || value > 1)) return fail(OCM_EINVAL, "OCM_OPT_FOLD_LN takes 0 (auto) or 1 (never)");
     if (h->opt[option] != value) h->graph_valid = false;  // a cached launch sequence was recorded under the old setting
     h->opt[option] = value;
+    return OCM_OK;
+}
+
+// (Re)build W' = W * gamma, c and d of every block whose LayerNorm / qkv / fc1 parameters changed since the last forward.
+static int ensure_folded(ocm_vit *h, hipStream_t s) {
+    if (!h->can_fold()) return OCM_OK;
+    for (int i = 0; i < h->L; ++i) {
+        BlockP &bp = h->blk[i];
+        if (!bp.fold_dirty) continue;
+        HIP_TRY(launch_fold_ln(h->ptr<float>(bp.qkv_w32), h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), h->ptr<float>(bp.qkv_b),
+                               h->ptr<char>(bp.qkv_wf), h->ptr<float>(bp.qkv_c), h->ptr<float>(bp.qkv_d), 3 * h->D, h->D, s));
+        HIP_TRY(launch_fold_ln(h->ptr<float>(bp.fc1_w32), h->ptr<float>(bp.ln2_g), h->ptr<float>(bp.ln2_b), h->ptr<float>(bp.fc1_b),
+                               h->ptr<char>(bp.fc1_wf), h->ptr<float>(bp.fc1_c), h->ptr<float>(bp.fc1_d), h->M, h->D, s));
+        bp.fold_dirty = false;
+    }
     return OCM_OK;
 }
 
@@ -293,6 +345,8 @@ struct Workspace {  // E = bf16 (OCM_PREC_BF16) or float (OCM_PREC_FP32)
     void *hid;    // [T][M] E GELU(fc1)
     float *lse;   // [B*H][N]
     float *qkv32; // [3][B][H][N][hd] fp32: the qkv tensor of heads that are not 64 wide (then q / k / vt are unused)
+    float *stats; // [2][T][D/64][2] row sums (sum x, sum x^2 per 64-column slot) of the residual stream at the LayerNorm site being
+                  // produced / consumed (folded LayerNorm: even sites in half 0, odd sites in half 1)
     size_t bytes;
 };
 
@@ -308,6 +362,13 @@ static Workspace carve(const ocm_vit *h, int batch, int n, char *base) {
     const size_t e = h->esz;
     w.x = (float *)take(T * h->D * 4);
     w.xn = take(T * h->D * e);
+    w.lse = (float *)take(BH * n * 4);
+    w.stats = h->can_fold() ? (float *)take(2 * T * (size_t)(h->D / 64) * 8) : nullptr;
+    // The attention operands (q, k, V^T or the fp32 qkv tensor, then the context) are dead once attn.proj has run, and the
+    // hidden activations only live from mlp.fc1 to mlp.fc2: the two groups share one region. ViT-S/16 at B = 64 in
+    // split-bf16: 123 MB instead of 195 MB, which with the 85 MB of weights keeps a forward's working set inside the
+    // 256 MiB Infinity Cache (weights and activations are then re-read from it rather than from HBM).
+    const size_t base_off = off;
     w.q = w.k = w.vt = nullptr;
     w.qkv32 = nullptr;
     if (h->hd == 64) {
@@ -318,8 +379,10 @@ static Workspace carve(const ocm_vit *h, int batch, int n, char *base) {
         w.qkv32 = (float *)take(3 * T * h->D * 4);
     }
     w.ctx = take(T * h->D * e);
+    const size_t attn_end = off;
+    off = base_off;
     w.hid = take(T * h->M * e);
-    w.lse = (float *)take(BH * n * 4);
+    if (off < attn_end) off = attn_end;
     w.bytes = off;
     return w;
 }
@@ -412,6 +475,58 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     return OCM_OK;
 }
 
+// Block.forward with both LayerNorms folded into the GEMMs that consume them (split-bf16 engines). On entry w.xn holds the
+// split pairs of x and stats site 2i its row sums; on exit (unless attn_only) the same for the block's output at site 2i+2.
+//   qkv  = rstd1 * (x W1'^T - mu1 c1) + d1          (attn.qkv with norm1 folded)
+//   x   += proj(attention)      -> x, split(x), sums at site 2i+1
+//   hid  = gelu(rstd2 * (x W2'^T - mu2 c2) + d2)    (mlp.fc1 with norm2 folded)
+//   x   += fc2(hid)             -> x, split(x), sums at site 2i+2
+// No LayerNorm kernel runs, and the N = D GEMMs are free to use tiles that do not own whole rows.
+static int run_block_folded(const ocm_vit *h, int i, const Workspace &w, float *x, int batch, int n, bool attn_only,
+                            float *out_attn, float *out_qkv, const int32_t *query_rows, int n_rows, float *out_rows,
+                            hipStream_t s) {
+    const BlockP &bp = h->blk[i];
+    const int D = h->D, H = h->H, T = batch * n, np = ocm_n_pad_for(h->prec, n), pc = h->prec;
+    const float scale = h->cfg.qk_scale;
+    // sites 2i (block input) and 2i+2 (block output) use half 0 of the statistics buffer, site 2i+1 (after attn.proj) half 1
+    float *st_in = w.stats, *st_mid = w.stats + (size_t)T * (D / 64) * 2, *st_out = w.stats;
+    LnFold ln1, ln2;
+    ln1.stats = st_in, ln1.c = h->ptr<float>(bp.qkv_c), ln1.d = h->ptr<float>(bp.qkv_d), ln1.inv_dim = 1.0f / D, ln1.eps = h->cfg.ln_eps;
+    ln2.stats = st_mid, ln2.c = h->ptr<float>(bp.fc1_c), ln2.d = h->ptr<float>(bp.fc1_d), ln2.inv_dim = 1.0f / D, ln2.eps = h->cfg.ln_eps;
+    ln1.nslot = ln2.nslot = D / 64;
+    const bool want_v = !(attn_only && !out_qkv);
+    if (h->hd != 64) {
+        float *qkv = out_qkv ? out_qkv : w.qkv32;
+        { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_wf), nullptr, nullptr, nullptr, nullptr, qkv, batch, n, np, H, h->hd, want_v, s, ln1)); }
+        { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention_generic(pc, qkv, attn_only ? nullptr : w.ctx, out_attn, query_rows, n_rows, out_rows, batch, n, H, h->hd, scale, s)); }
+        if (attn_only) return OCM_OK;
+    } else {
+        void *vt_dst = want_v ? w.vt : nullptr;
+        { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_wf), nullptr, w.q, w.k, vt_dst, out_qkv, batch, n, np, H, 64, want_v, s, ln1)); }
+        if (out_rows && !out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s)); }
+        if (attn_only) {
+            if (out_attn) {
+                { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s)); }
+                { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
+                if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
+            }
+            return OCM_OK;
+        }
+        { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s)); }
+        if (out_attn) {
+            { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
+            if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
+        }
+    }
+    StatsOut so_mid, so_out;
+    so_mid.xs = w.xn, so_mid.stats = st_mid;
+    so_out.xs = w.xn, so_out.stats = st_out;
+    { PROF(OCM_K_PROJ, s); HIP_TRY(launch_linear(pc, w.ctx, h->ptr<char>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s, LnFold(), so_mid)); }
+    { PROF(OCM_K_FC1, s); HIP_TRY(launch_linear(pc, w.xn, h->ptr<char>(bp.fc1_wf), nullptr, nullptr, w.hid, T, h->M, D, OCM_EPI_BIAS_GELU_BF16, s, ln2)); }
+    { PROF(OCM_K_FC2, s); HIP_TRY(launch_linear(pc, w.hid, h->ptr<char>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s, LnFold(), so_out)); }
+    return OCM_OK;
+}
+
 static int check_tiles(const ocm_vit *h, const ocm_vit_io *io, int *n_out) {
     if (!io) return fail(OCM_EINVAL, "io is null");
     if (!io->image) return fail(OCM_EINVAL, "io->image is null");
@@ -425,7 +540,8 @@ static int check_tiles(const ocm_vit *h, const ocm_vit_io *io, int *n_out) {
     return OCM_OK;
 }
 
-static int run_prepare(const ocm_vit *h, const ocm_vit_io *io, float *x, int n, hipStream_t s) {
+static int run_prepare(const ocm_vit *h, const ocm_vit_io *io, float *x, int n, hipStream_t s, void *xs = nullptr,
+                       float *stats = nullptr) {
     PatchArgs pa{io->image, io->img_stride_b, io->img_stride_c, io->img_stride_y, io->tile_origins,
                  io->batch, io->tile_h / h->p, io->tile_w / h->p, h->p, h->C};
     if (io->patch_mask) {
@@ -433,9 +549,14 @@ static int run_prepare(const ocm_vit *h, const ocm_vit_io *io, float *x, int n, 
         pa.mask = io->patch_mask;
         pa.mask_tok = h->ptr<float>(h->mask_tok);
     }
-    HIP_TRY(launch_cls_rows(h->ptr<float>(h->cls), io->pos_embed, x, io->batch, n, h->D, s));
+    StatsOut so;
+    so.xs = xs, so.stats = stats;
+    if (stats)  // folded first LayerNorm: the token rows also leave as split pairs with their row sums
+        HIP_TRY(launch_cls_rows_stats(h->ptr<float>(h->cls), io->pos_embed, x, xs, stats, io->batch, n, h->D, s));
+    else
+        HIP_TRY(launch_cls_rows(h->ptr<float>(h->cls), io->pos_embed, x, io->batch, n, h->D, s));
     PROF(OCM_K_PATCH, s);
-    HIP_TRY(launch_patch_embed(h->prec, pa, h->ptr<char>(h->pe_w), h->ptr<float>(h->pe_b), io->pos_embed, x, h->D, s));
+    HIP_TRY(launch_patch_embed(h->prec, pa, h->ptr<char>(h->pe_w), h->ptr<float>(h->pe_b), io->pos_embed, x, h->D, s, so));
     return OCM_OK;
 }
 
@@ -480,8 +601,11 @@ static int enqueue_forward(ocm_vit *h, const ocm_vit_io *io, int n, hipStream_t 
     const bool attn_only = fl & OCM_LAST_ATTN_ONLY;
     int rc;
     const Workspace w = carve(h, B, n, (char *)io->workspace);
-    if ((rc = run_prepare(h, io, w.x, n, s))) return rc;
     const size_t T = (size_t)B * n;
+    const bool fold = h->folding();
+    if (fold) {
+        if ((rc = run_prepare(h, io, w.x, n, s, w.xn, w.stats))) return rc;
+    } else if ((rc = run_prepare(h, io, w.x, n, s))) return rc;
     bool xn_ready = false;  // w.xn holds the next block's norm1(x) (fused into the previous fc2)
     for (int i = 0; i < L; ++i) {
         const int slot = i - (L - io->n_last);  // >= 0 for the returned blocks
@@ -490,8 +614,10 @@ static int enqueue_forward(ocm_vit *h, const ocm_vit_io *io, int n, hipStream_t 
         float *oq = (ret && (fl & OCM_OUT_QKV)) ? io->out_qkv + (size_t)slot * 3 * B * h->H * n * h->hd : nullptr;
         float *orow = (last && (fl & OCM_OUT_ROWS)) ? io->out_rows : nullptr;
         const float *ng = last ? nullptr : h->ptr<float>(h->blk[i + 1].ln1_g), *nb = last ? nullptr : h->ptr<float>(h->blk[i + 1].ln1_b);
-        if ((rc = run_block(h, i, w, w.x, B, n, attn_only && last, oa, oq, io->query_rows, io->n_rows, orow, s, xn_ready, ng, nb,
-                            &xn_ready)))
+        if (fold) {
+            if ((rc = run_block_folded(h, i, w, w.x, B, n, attn_only && last, oa, oq, io->query_rows, io->n_rows, orow, s))) return rc;
+        } else if ((rc = run_block(h, i, w, w.x, B, n, attn_only && last, oa, oq, io->query_rows, io->n_rows, orow, s, xn_ready, ng, nb,
+                                   &xn_ready)))
             return rc;
         if (ret && (fl & OCM_OUT_FEAT)) {
             PROF(OCM_K_LN, s);
@@ -533,6 +659,9 @@ extern "C" int ocm_vit_forward(ocm_vit_t *h, const ocm_vit_io *io) {
         return fail(OCM_EINVAL, "OCM_OUT_ROWS needs out_rows and n_rows > 0");
     if ((rc = check_ws(h, B, n, io->workspace, io->workspace_bytes))) return rc;
     hipStream_t s = (hipStream_t)io->stream;
+    // folded-LayerNorm operands of blocks whose parameters changed: rebuilt on the caller's stream, ahead of (and never
+    // inside) a captured launch sequence, which only holds their addresses
+    if (h->folding() && (rc = ensure_folded(h, s))) return rc;
     if (!(fl & OCM_USE_GRAPH) || g_prof.on) return enqueue_forward(h, io, n, s);
 
     // ---- hipGraph path: replay when nothing the launch arguments depend on has changed --------------------

@@ -25,6 +25,13 @@
 // Development instrumentation (make stamps -> exp_libs/stamps.so, tools/stamps.py): thread 0 of every workgroup
 // records the shader clock at the phase boundaries of gemm_kernel. Compiled out unless -DOCM_GEMM_STAMPS.
 #ifdef OCM_GEMM_STAMPS
+// per-wave timeline of ONE K step (the middle one) of the LDS-DMA loop: [workgroup][wave][point]
+__device__ unsigned long long g_wstamps[512 * 16 * 8];
+#define WSTAMP(k)                                                                                       \
+    do {                                                                                                \
+        if (t == nsteps / 2 && (threadIdx.x & 63) == 0 && blockIdx.x < 512)                              \
+            g_wstamps[(blockIdx.x * 16 + (threadIdx.x >> 6 & 15)) * 8 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
 __device__ unsigned long long g_stamps[8192 * 8];
 #define STAMP(i)                                                                                        \
     do {                                                                                                \
@@ -32,6 +39,7 @@ __device__ unsigned long long g_stamps[8192 * 8];
     } while (0)
 #else
 #define STAMP(i) ((void)0)
+#define WSTAMP(k) ((void)0)
 #endif
 
 template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
@@ -473,41 +481,94 @@ __device__ __forceinline__ void gemm_mainloop_dma(const E *__restrict__ A, int64
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = bv[j][SWAP ? e : 0];
     int bc = 0, bi = D % NSTAGE;  // stage computed next / stage filled next
+#ifdef OCM_GEMM_STAMPS
+    unsigned long long stamp_wait = 0;
+#endif
     for (int t = 0; t < nsteps; ++t) {
         // own DMAs of step t have landed once at most the (younger) steps t+1 .. t+D-1 are pending
         const int younger = min(D - 1, nsteps - 1 - t);
+#ifdef OCM_GEMM_STAMPS
+        const unsigned long long tw0 = __builtin_readcyclecounter();
+#endif
+        WSTAMP(0);  // step entered
         wait_vm_steps<LPS, NSTAGE - 2>(younger);
+        WSTAMP(1);  // own DMAs landed
+#ifdef OCM_GEMM_STAMPS
+        const unsigned long long tw1 = __builtin_readcyclecounter();
+#endif
         raw_barrier();
 #ifdef OCM_GEMM_STAMPS
         if (t == 0) STAMP(6);  // first tile landed
+        if (t > 0) {  // slot 7: cycles this wave spent waiting for its own DMAs (low 32 bits) and at the barrier (high 32 bits), steps 1..
+            const unsigned long long tw2 = __builtin_readcyclecounter();
+            stamp_wait += ((tw2 - tw1) << 32) | ((tw1 - tw0) & 0xFFFFFFFFull);
+        }
 #endif
+        WSTAMP(2);  // barrier passed
 #if !defined(OCM_ABL) || OCM_ABL != 2  // ablation 2: no DMA after the prologue
         if (t + D < nsteps) OCM_DMA_ISSUE(t + D, bi);
 #endif
         __builtin_amdgcn_sched_barrier(0);
+        WSTAMP(3);  // DMA issued
         compute(bc);
+#ifdef OCM_GEMM_STAMPS
+        if (t == nsteps / 2) {  // wait for the last MFMA's result, then stamp
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("v_mov_b32 %0, %0\n\ts_nop 0" : "+v"(acc[TM - 1][TN - 1][15]));
+            WSTAMP(4);
+        }
+#endif
         bc = bc + 1 == NSTAGE ? 0 : bc + 1;
         bi = bi + 1 == NSTAGE ? 0 : bi + 1;
     }
     raw_barrier();  // every wave is done reading: the epilogue may reuse the LDS
+#ifdef OCM_GEMM_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + 7] = stamp_wait;
+#endif
 #undef OCM_DMA_ISSUE
 }
 
-// Epilogue: after the main loop's last barrier the operand LDS is free, so the waves drop their fp32
-// accumulator tiles into a row-major LDS image and the epilogue functor reads whole 16-B / 32-B row
-// chunks back and issues full-width, fully coalesced global loads/stores with the index math done once
-// per chunk instead of once per element. When BM x BN fp32 fits the operand LDS this is one pass over
-// the whole tile; bigger tiles go band by band (RB rows of the tile per pass, or CB feature columns when
-// the accumulator is transposed), double-buffered so one LDS-only barrier per pass is enough.
-template <class Cfg, bool SWAP, class Epi>
+// Per-row and per-column scalars of an epilogue (Epi::ROWTAB: the folded LayerNorm's (mu, rstd) per row and (c, d) per
+// column). They are REQUESTED at kernel start — thread t < BM the row sums of row m0 + t (raw slots: the arithmetic on
+// them waits until the epilogue, so that no wait for these loads sits in front of the main loop), thread t < BN the column
+// pair of column n0 + t — and published in two small LDS tables behind the operand area, ahead of the barrier that also
+// publishes the accumulator image.
+constexpr int EPI_MAXS = 6;
+struct EpiPre {
+    f32x2 raw[EPI_MAXS];
+    f32x2 cd;
+};
+template <class Cfg, class Epi>
+__device__ __forceinline__ EpiPre epi_prefetch(const Epi &epi, int m0, int n0, int M, int N) {
+    EpiPre p;
+#pragma unroll
+    for (int i = 0; i < EPI_MAXS; ++i) p.raw[i] = f32x2{0.f, 0.f};
+    p.cd = f32x2{0.f, 0.f};
+    if constexpr (Epi::ROWTAB) {
+        if (threadIdx.x < Cfg::BM) epi.row_raw(min(m0 + (int)threadIdx.x, M - 1), p.raw);
+        if (threadIdx.x < Cfg::BN) p.cd = epi.col_entry(min(n0 + (int)threadIdx.x, N - 1));
+    }
+    return p;
+}
+
+// LDS_AVAIL: bytes of LDS the kernel owns (the register-staged kernels: Cfg::LDS_BYTES; the LDS-DMA kernels: their ring)
+template <class Cfg, bool SWAP, class Epi, int LDS_AVAIL = Cfg::LDS_BYTES>
 __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::TN], char *smem, const Epi &epi, int m0,
-                                             int n0) {
+                                             int n0, bool active = true, const EpiPre *pre = nullptr) {
+    f32x2 *rowtab = (f32x2 *)(smem + LDS_AVAIL), *coltab = rowtab + Cfg::BM;
+    if constexpr (Epi::ROWTAB) {
+        if (threadIdx.x < Cfg::BM) rowtab[threadIdx.x] = epi.row_final(pre->raw);
+        if (threadIdx.x < Cfg::BN) coltab[threadIdx.x] = pre->cd;
+    }
+    // `active` false (workgroup-uniform per wave): a wave that holds no accumulators (the loader waves of the
+    // wave-specialised kernel) only keeps the barrier count of the passes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / Cfg::WAVES_N, wn = wave % Cfg::WAVES_N;
     const int r = lane & 31, h = lane >> 5;
-    if constexpr (Cfg::BM * Cfg::BN * 4 <= Cfg::LDS_BYTES) {
+    if constexpr (Cfg::BM * Cfg::BN * 4 <= LDS_AVAIL) {
         constexpr int COLS = SWAP ? Cfg::BM : Cfg::BN;
         float *C = (float *)smem;
+        if (active)
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
@@ -521,15 +582,16 @@ __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::T
         STAMP(2);
         lds_barrier();
         STAMP(3);
-        epi.template run<PassCfg<Cfg::BM, Cfg::BN, Cfg::NT>>((const float *)C, m0, n0);
+        if (active) epi.template run<PassCfg<Cfg::BM, Cfg::BN, Cfg::NT>>((const float *)C, m0, n0, rowtab, coltab);
     } else if constexpr (!SWAP) {
         constexpr int PASS = Cfg::RB * Cfg::BN * 4;  // one band of RB rows
-        static_assert(PASS <= Cfg::LDS_BYTES, "a row band must fit the operand LDS");
-        constexpr int NBUF = 2 * PASS <= Cfg::LDS_BYTES ? 2 : 1;
+        static_assert(PASS <= LDS_AVAIL, "a row band must fit the operand LDS");
+        constexpr int NBUF = 2 * PASS <= LDS_AVAIL ? 2 : 1;
 #pragma unroll
         for (int i = 0; i < Cfg::TM; ++i) {
             if (NBUF == 1 && i) lds_barrier();  // the band's readers are done
             float *C = (float *)(smem + (i % NBUF) * PASS);
+            if (active)
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) {
                 const int col = (j * Cfg::WAVES_N + wn) * 32 + r;
@@ -537,16 +599,17 @@ __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::T
                 for (int e = 0; e < 16; ++e) C[(wm * 32 + acc_row32(e, h)) * Cfg::BN + col] = acc[i][j][e];
             }
             lds_barrier();  // also orders pass i-2's reads of this buffer before pass i's writes (see above)
-            epi.template run<PassCfg<Cfg::RB, Cfg::BN, Cfg::NT>>((const float *)C, m0 + i * Cfg::RB, n0);
+            if (active) epi.template run<PassCfg<Cfg::RB, Cfg::BN, Cfg::NT>>((const float *)C, m0 + i * Cfg::RB, n0, rowtab + i * Cfg::RB, coltab);
         }
     } else {
         constexpr int PASS = Cfg::CB * Cfg::BM * 4;  // one band of CB feature rows of the transposed tile
-        static_assert(PASS <= Cfg::LDS_BYTES, "a column band must fit the operand LDS");
-        constexpr int NBUF = 2 * PASS <= Cfg::LDS_BYTES ? 2 : 1;
+        static_assert(PASS <= LDS_AVAIL, "a column band must fit the operand LDS");
+        constexpr int NBUF = 2 * PASS <= LDS_AVAIL ? 2 : 1;
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) {
             if (NBUF == 1 && j) lds_barrier();
             float *C = (float *)(smem + (j % NBUF) * PASS);
+            if (active)
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i) {
                 const int col = (i * Cfg::WAVES_M + wm) * 32 + r;
@@ -554,7 +617,7 @@ __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::T
                 for (int e = 0; e < 16; ++e) C[(wn * 32 + acc_row32(e, h)) * Cfg::BM + col] = acc[i][j][e];
             }
             lds_barrier();
-            epi.template run<PassCfg<Cfg::BM, Cfg::CB, Cfg::NT>>((const float *)C, m0, n0 + j * Cfg::CB);
+            if (active) epi.template run<PassCfg<Cfg::BM, Cfg::CB, Cfg::NT>>((const float *)C, m0, n0 + j * Cfg::CB, rowtab, coltab + j * Cfg::CB);
         }
     }
 }
@@ -569,6 +632,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_dma_kernel(const E *__restrict__
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
+    const EpiPre pre = epi_prefetch<Cfg>(epi, m0, n0, M, N);
     STAMP(0);
 #if defined(OCM_ABL) && OCM_ABL == 4  // ablation 4: epilogue only
 #pragma unroll
@@ -587,7 +651,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_dma_kernel(const E *__restrict__
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-    run_epilogue<Cfg, SWAP>(acc, smem, epi, m0, n0);
+    run_epilogue<Cfg, SWAP, Epi, NSTAGE * (Cfg::BM + Cfg::BN) * 128>(acc, smem, epi, m0, n0, true, &pre);
 #endif
     STAMP(4);
 #ifdef OCM_GEMM_STAMPS
@@ -607,10 +671,11 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const E *__rest
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
+    const EpiPre pre = epi_prefetch<Cfg>(epi, m0, n0, M, N);
     STAMP(0);
     gemm_mainloop<Cfg, E, SWAP, KSTEPS>(al, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
     STAMP(1);  // prologue + K loop done
-    run_epilogue<Cfg, SWAP>(acc, smem, epi, m0, n0);  // STAMP 2: accumulators staged, 3: barrier passed
+    run_epilogue<Cfg, SWAP>(acc, smem, epi, m0, n0, true, &pre);  // STAMP 2: accumulators staged, 3: barrier passed
     STAMP(4);  // epilogue body issued
 #ifdef OCM_GEMM_STAMPS
     __builtin_amdgcn_s_waitcnt(0);

@@ -94,6 +94,38 @@ __device__ __forceinline__ void store_act1(sp32 *, char *rowp, int col, float v)
 //   MODE 2: OE out = gelu(acc)  MODE 3: OE out = acc          (OE = operand type of the next GEMM)
 // Every lane moves 16 B per chunk. The residual of ALL of a lane's chunks is requested in one burst
 // before the first use (one exposed L2 round trip instead of one per unrolled group).
+// (mu, rstd) of row m from the sums its producers accumulated (launch.h: LnFold)
+// Folded-LayerNorm helpers (launch.h: LnFold). The row sums of row m: all slot loads in flight at once (clamped indices, no
+// run-time trip count: a loop would wait for every load in turn), added in index order LATER (ln_row_final): deterministic.
+__device__ __forceinline__ void ln_row_raw(const LnFold &ln, int64_t m, f32x2 (&raw)[EPI_MAXS]) {
+    if (!ln.stats) return;
+    const f32x2 *sp = (const f32x2 *)ln.stats + m * ln.nslot;
+    if (ln.nslot <= EPI_MAXS) {
+        const int last = ln.nslot - 1;
+#pragma unroll
+        for (int i = 0; i < EPI_MAXS; ++i) {
+            const f32x2 v = sp[min(i, last)];
+            raw[i] = i <= last ? v : f32x2{0.f, 0.f};
+        }
+    } else {  // wide rows (ViT-B: 12 slots): summed here
+        f32x2 sm = sp[0];
+        for (int i = 1; i < ln.nslot; ++i) sm += sp[i];
+        raw[0] = sm;
+    }
+}
+__device__ __forceinline__ f32x2 ln_row_final(const LnFold &ln, const f32x2 (&raw)[EPI_MAXS]) {
+    if (!ln.stats) return f32x2{0.f, 1.f};
+    f32x2 sm = raw[0];
+#pragma unroll
+    for (int i = 1; i < EPI_MAXS; ++i) sm += raw[i];
+    const float mu = sm[0] * ln.inv_dim;
+    const float var = fmaxf(fmaf(-mu, mu, sm[1] * ln.inv_dim), 0.f);
+    return f32x2{mu, 1.0f / sqrtf(var + ln.eps)};
+}
+__device__ __forceinline__ f32x2 ln_col_entry(const LnFold &ln, int n) {
+    return ln.stats ? f32x2{ln.c[n], ln.d[n]} : f32x2{0.f, 0.f};
+}
+
 template <int MODE, class OE>
 struct EpiLinear {
     const float *bias;
@@ -102,8 +134,13 @@ struct EpiLinear {
     int M, N;
     int64_t ldo;
     int wt = 0;  // activation outputs with write-through (sc1) stores
+    LnFold ln;   // MODE 2 / 3: the LayerNorm in front of this layer, folded (the accumulator then starts at 0, not at the bias)
+    static constexpr bool ROWTAB = (MODE == 2 || MODE == 3);
+    __device__ __forceinline__ void row_raw(int m, f32x2 (&raw)[EPI_MAXS]) const { ln_row_raw(ln, m, raw); }
+    __device__ __forceinline__ f32x2 row_final(const f32x2 (&raw)[EPI_MAXS]) const { return ln_row_final(ln, raw); }
+    __device__ __forceinline__ f32x2 col_entry(int n) const { return ln_col_entry(ln, n); }
     template <class Cfg>
-    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
+    __device__ __forceinline__ void run(const float *C, int m0, int n0, const f32x2 *rowtab, const f32x2 *coltab) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
         constexpr bool ACT_OUT = (MODE == 2 || MODE == 3);
         constexpr int W = ACT_OUT ? Elem<OE>::EPW : 4;  // columns per lane
@@ -130,6 +167,22 @@ struct EpiLinear {
             } else {
                 f32x4 v1 = v0;
                 if (W == 8) v1 = *(const f32x4 *)(C + row * BN + col + 4);
+                if (ln.stats) {  // LN(x) W^T + b = rstd * (x W'^T - mu c) + d
+                    const f32x2 mr = rowtab[row];
+                    const float mu = mr[0], rstd = mr[1];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x2 cd = coltab[col + e];
+                        v0[e] = fmaf(rstd, fmaf(-mu, cd[0], v0[e]), cd[1]);
+                    }
+                    if (W == 8) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x2 cd = coltab[col + 4 + e];
+                            v1[e] = fmaf(rstd, fmaf(-mu, cd[0], v1[e]), cd[1]);
+                        }
+                    }
+                }
                 if (MODE == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; e += 2) {
@@ -152,14 +205,95 @@ struct EpiLinear {
     }
 };
 
+// x = resid + acc (bias in the accumulator), fp32 in place — and, for the LayerNorm that follows and is folded into ITS
+// consumer: the split pairs of x and the row sums (sum x, sum x^2). Eight lanes own a row of the tile (BN / 64 chunks of
+// eight columns each: every load and store is 16 bytes wide), reduce their partial sums by shuffles and store them in the
+// tile's slots of the row (launch.h: LnFold — one slot per 64 columns, no atomics, nothing to zero). Both outputs are
+// written through (sc1, `wt`): 38 MB of dirty lines per launch at ViT-S/16 B = 64 would otherwise be flushed at the kernel
+// boundary, in front of the consumer (measured: attn.qkv / mlp.fc1 7-9 us slower per launch with plain stores).
+template <class OE>
+struct EpiResidStats {
+    static constexpr bool ROWTAB = false;
+    const float *bias;
+    const float *resid;
+    float *x;
+    void *xs;
+    float *stats;
+    int M, N;
+    int wt = 3;  // bit 0: x, bit 1: xs with write-through stores
+    __device__ __forceinline__ static void st16(void *p, const f32x4 &v, bool through) {
+        if (through)
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+        else
+            *(f32x4 *)p = v;
+    }
+    template <class Cfg>
+    __device__ __forceinline__ void run(const float *C, int m0, int n0, const f32x2 *, const f32x2 *) const {
+        constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, NV = BN / 64, RPP = NT / 8;
+        static_assert(BN % 64 == 0 && NT % 64 == 0, "eight lanes x eight columns per chunk");
+        const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+#pragma unroll 2
+        for (int r0 = 0; r0 < BM; r0 += RPP) {
+            const int row = r0 + grp, m = m0 + row;
+            const bool ok = row < BM && m < M;  // no barriers below; the shuffles are executed by every lane
+            const int64_t mo = (int64_t)min(m, M - 1) * N;
+            f32x4 v[NV][2];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                v[i][0] = *(const f32x4 *)(resid + mo + n0 + sub * 8 + i * 64);
+                v[i][1] = *(const f32x4 *)(resid + mo + n0 + sub * 8 + i * 64 + 4);
+            }
+            float s1 = 0.f, s2 = 0.f;
+            char *rowp = (char *)xs + mo * (int)sizeof(OE);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int n = n0 + sub * 8 + i * 64;
+                const float *cp = C + min(row, BM - 1) * BN + sub * 8 + i * 64;
+                v[i][0] += *(const f32x4 *)cp;
+                v[i][1] += *(const f32x4 *)(cp + 4);
+                if (ok) {
+                    st16(x + mo + n, v[i][0], wt & 1);
+                    st16(x + mo + n + 4, v[i][1], wt & 1);
+                    if constexpr (Elem<OE>::MODE == 2) {
+                        bf16x8 hi, lo;
+                        split8(v[i][0], v[i][1], hi, lo);
+                        st16(rowp + sp_off(n), __builtin_bit_cast(f32x4, hi), wt & 2);
+                        st16(rowp + sp_off(n) + 64, __builtin_bit_cast(f32x4, lo), wt & 2);
+                    } else if constexpr (Elem<OE>::MODE == 1) {
+                        *(f32x4 *)(rowp + n * 4) = v[i][0];
+                        *(f32x4 *)(rowp + n * 4 + 16) = v[i][1];
+                    } else {
+                        *(bf16x8 *)(rowp + n * 2) = cvt8(v[i][0], v[i][1]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1 += v[i][0][e] + v[i][1][e];
+                    s2 = fmaf(v[i][0][e], v[i][0][e], fmaf(v[i][1][e], v[i][1][e], s2));
+                }
+            }
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) {
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+            }
+            if (ok && sub < NV) {  // the tile's first slot carries its sums, its other slots zeros (launch.h: LnFold)
+                const f32x2 val = {sub ? 0.f : s1, sub ? 0.f : s2};
+                *((f32x2 *)stats + (int64_t)m * (N >> 6) + (n0 >> 6) + sub) = val;
+            }
+        }
+    }
+};
+
 template <class Cfg, class E, bool SWAP, int KSTEPS, class ALoad, class Epi>
 static hipError_t launch_gemm_ks(const ALoad &al, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
                                  hipStream_t s) {
     auto kern = gemm_kernel<Cfg, E, SWAP, KSTEPS, ALoad, Epi>;
+    constexpr int LDS = Cfg::LDS_BYTES + (Epi::ROWTAB ? (Cfg::BM + Cfg::BN) * 8 : 0);  // + the epilogue's row / column tables
     static unsigned long long optin = 0;
-    if (hipError_t e = ensure_lds_optin((const void *)kern, Cfg::LDS_BYTES, optin); e != hipSuccess) return e;
+    if (hipError_t e = ensure_lds_optin((const void *)kern, LDS, optin); e != hipSuccess) return e;
     const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
-    kern<<<dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, s>>>(al, w, ldw, M, N, K, epi);
+    kern<<<dim3(tiles), dim3(Cfg::NT), LDS, s>>>(al, w, ldw, M, N, K, epi);
     return hipGetLastError();
 }
 
@@ -187,7 +321,7 @@ static hipError_t launch_gemm(const ALoad &al, const E *w, int64_t ldw, int M, i
 template <class Cfg, class E, int KSTEPS, int NSTAGE, class Epi>
 static hipError_t launch_gemm_dma_ks(const E *a, int64_t lda, const E *w, int64_t ldw, int M, int N, int K, const Epi &epi,
                                      hipStream_t s) {
-    constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
+    constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128 + (Epi::ROWTAB ? (Cfg::BM + Cfg::BN) * 8 : 0);  // + the epilogue's row / column tables
     static_assert(LDS <= 160 * 1024, "LDS ring exceeds the CU");
     const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((N + Cfg::BN - 1) / Cfg::BN);
     auto kern = gemm_dma_kernel<Cfg, E, false, KSTEPS, NSTAGE, Epi>;
@@ -202,24 +336,24 @@ static hipError_t launch_gemm_dma(const E *a, int64_t lda, const E *w, int64_t l
                                   hipStream_t s) {
     if (K % Elem<E>::KROW) return hipErrorInvalidValue;
     switch (K / Elem<E>::KROW) {
-        case 6: return launch_gemm_dma_ks<Cfg, E, 6, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
-        case 12: return launch_gemm_dma_ks<Cfg, E, 12, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
-        case 24: return launch_gemm_dma_ks<Cfg, E, 24, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
-        case 48: return launch_gemm_dma_ks<Cfg, E, 48, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
+        case 6: return launch_gemm_dma_ks<Cfg, E, 6, NSTAGE, Epi>(a, lda, w, ldw, M, N, K, epi, s);
+        case 12: return launch_gemm_dma_ks<Cfg, E, 12, NSTAGE, Epi>(a, lda, w, ldw, M, N, K, epi, s);
+        case 24: return launch_gemm_dma_ks<Cfg, E, 24, NSTAGE, Epi>(a, lda, w, ldw, M, N, K, epi, s);
+        case 48: return launch_gemm_dma_ks<Cfg, E, 48, NSTAGE, Epi>(a, lda, w, ldw, M, N, K, epi, s);
         default: break;
     }
-    return launch_gemm_dma_ks<Cfg, E, 0, NSTAGE>(a, lda, w, ldw, M, N, K, epi, s);
+    return launch_gemm_dma_ks<Cfg, E, 0, NSTAGE, Epi>(a, lda, w, ldw, M, N, K, epi, s);
 }
 
 typedef GemmCfg<256, 128, 4, 2> Cfg256x128;
+// N = 384 outputs (attn.proj, mlp.fc2) at ~12 k rows: 198 tiles, one 8-wave workgroup per CU, wave tile 32 x 96. Per K step
+// 40 KiB of operands for 1152 cycles of MFMA per SIMD, against 56 KiB for the 64 x 384 full-row tile
+typedef GemmCfg<128, 192, 4, 2> Cfg128x192;
 typedef GemmCfg<128, 256, 2, 4> Cfg128x256;
 
-template <int MODE, class E>
-static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, const float *resid, void *out, int M,
-                                     int N, int K, hipStream_t s) {
+template <int MODE, class E, class Epi>
+static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int M, int N, int K, hipStream_t s) {
     RowLoader<E> al{a, K};
-    EpiLinear<MODE, E> epi{bias, resid, out, M, N, N};
-    epi.wt = ocm_wt_mask() & 1;
     if constexpr (Elem<E>::MODE == 2) {
 #ifdef OCM_DEV
         switch (OCM_KNOB(0)) {  // development: force a variant (tools/microbench_x3.py)
@@ -231,6 +365,7 @@ static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, 
             case 8: if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 3>(a, K, w, K, M, N, K, epi, s); break;
             case 9: if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 4>(a, K, w, K, M, N, K, epi, s); break;
             case 10: if (N % 64 == 0) return launch_gemm_dma<Cfg64x64, E, 4>(a, K, w, K, M, N, K, epi, s); break;
+            case 11: if (N == 384) return launch_gemm_dma<Cfg128x192, E, 3>(a, K, w, K, M, N, K, epi, s); break;
             default: break;
         }
 #endif
@@ -247,6 +382,12 @@ static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, 
         }
         if (big_tiles_pay(M, N, K))  // ViT-B at 384^2: 256x256 tiles, one 8-wave workgroup per CU (fc1 1020 -> 944 us)
             return launch_gemm_dma<Cfg256x256, E, 2>(a, K, w, K, M, N, K, epi, s);
+        // Narrow outputs (attn.proj / mlp.fc2 of ViT-S: N = 384) with too few rows for 512 tiles of 128 x 128: 128 x 192
+        // tiles, one 8-wave workgroup per CU on a three-stage LDS-DMA ring. Per K step 40 KiB of operands for 1152 cycles
+        // of MFMA per SIMD (56 KiB for the 64 x 384 full-row tile, 64 KiB for two 64 x 128 tiles): ViT-S/16 at B = 64,
+        // in the forward, mlp.fc2 64 -> 49 us, attn.proj 28.5 -> 21.5 us against the full-row GEMM + LayerNorm kernels
+        if (N % 192 == 0 && N / 192 <= 2 && M >= 4096 && (long)((M + 127) / 128) * ((N + 127) / 128) < 512)
+            return launch_gemm_dma<Cfg128x192, E, 3>(a, K, w, K, M, N, K, epi, s);
         if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512)
             return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
     }
@@ -266,14 +407,37 @@ reg_staged:
     return launch_gemm<Cfg64x64, E, false>(al, w, K, M, N, K, epi, s);
 }
 
+template <int MODE, class E>
+static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, const float *resid, void *out, int M,
+                                     int N, int K, hipStream_t s, const LnFold &ln = LnFold()) {
+    EpiLinear<MODE, E> epi{bias, resid, out, M, N, N};
+    epi.wt = ocm_wt_mask() & 1;
+    if (ln.stats) {  // folded LayerNorm: the bias travels in ln.d, the accumulator starts at zero
+        epi.ln = ln;
+        epi.bias = nullptr;
+        if (OCM_KNOB(6) == 1) epi.ln.stats = nullptr;  // development timing probe (wrong results): fold arithmetic off
+        if (OCM_KNOB(6) == 2) epi.ln.nslot = 1;         // development timing probe (wrong results): one slot load per row
+    }
+    return launch_linear_epi<MODE, E>(a, w, epi, M, N, K, s);
+}
+
+// epilogue 4 (internal): x = resid + acc + bias in place, plus split pairs and row sums of x (StatsOut)
 template <class E>
 hipError_t launch_linear_e(const E *a, const E *w, const float *bias, const float *resid, void *out, int M, int N,
-                                  int K, int epilogue, hipStream_t s) {
+                                  int K, int epilogue, hipStream_t s, const LnFold &ln, const StatsOut &so) {
     switch (epilogue) {
         case 0: return launch_linear_mode<0, E>(a, w, bias, resid, out, M, N, K, s);
-        case 1: return launch_linear_mode<1, E>(a, w, bias, resid, out, M, N, K, s);
-        case 2: return launch_linear_mode<2, E>(a, w, bias, resid, out, M, N, K, s);
-        case 3: return launch_linear_mode<3, E>(a, w, bias, resid, out, M, N, K, s);
+        case 1:
+            if (so.stats) {
+                if (N % 64) return hipErrorInvalidValue;
+                EpiResidStats<E> epi{bias, resid, (float *)out, so.xs, so.stats, M, N};
+                epi.wt = OCM_KNOB(5) ? OCM_KNOB(5) - 1 : 0;  // development knob 5: 1 + write-through mask. Plain stores ship: x written
+                // through costs the producers 3 us per launch and buys the consumers nothing (in-forward A/B)
+                return launch_linear_epi<1, E>(a, w, epi, M, N, K, s);
+            }
+            return launch_linear_mode<1, E>(a, w, bias, resid, out, M, N, K, s);
+        case 2: return launch_linear_mode<2, E>(a, w, bias, resid, out, M, N, K, s, ln);
+        case 3: return launch_linear_mode<3, E>(a, w, bias, resid, out, M, N, K, s, ln);
     }
     return hipErrorInvalidValue;
 }
@@ -311,6 +475,7 @@ hipError_t launch_linear_ld_e(const E *a, int64_t lda, const E *w, const float *
 // layernorm_v4_kernel (half a wavefront per row, the row in registers), on exactly the fp32 values written to x.
 template <class OE, int D_>
 struct EpiResidLN {
+    static constexpr bool ROWTAB = false;
     const float *bias;
     const float *resid;
     float *x;           // [M][D] fp32 residual stream out (may alias resid)
@@ -320,7 +485,7 @@ struct EpiResidLN {
     float eps;
     int wt = 0;         // bit 0: xn with write-through stores
     template <class Cfg>
-    __device__ __forceinline__ void run(const float *C, int m0, int) const {
+    __device__ __forceinline__ void run(const float *C, int m0, int, const f32x2 *, const f32x2 *) const {
         constexpr int BM = Cfg::BM, NT = Cfg::NT, NV = D_ / 128;
         static_assert(Cfg::BN == D_ && D_ % 128 == 0, "full rows, float4 lanes");
         const int sub = threadIdx.x & 31, half = threadIdx.x >> 5;  // half-wavefront per row
@@ -393,30 +558,38 @@ struct EpiResidLN {
     }
 };
 
+// One full-row GEMM + residual + LayerNorm launch on tile configuration Cfg. `loop`: 0 = register-staged main loop,
+// 2 = two-stage LDS-DMA ring.
+template <class Cfg, class E, int D_>
+static hipError_t launch_resid_ln_cfg(int loop, const E *a, const E *w, const EpiResidLN<E, D_> &epi, int M, int K,
+                                      hipStream_t s) {
+    if (K % Elem<E>::KROW) return hipErrorInvalidValue;
+    if (loop == 2) {
+        switch (K / Elem<E>::KROW) {
+            case 12: return launch_gemm_dma_ks<Cfg, E, 12, 2>(a, K, w, K, M, D_, K, epi, s);
+            case 48: return launch_gemm_dma_ks<Cfg, E, 48, 2>(a, K, w, K, M, D_, K, epi, s);
+            default: return launch_gemm_dma_ks<Cfg, E, 0, 2>(a, K, w, K, M, D_, K, epi, s);
+        }
+    }
+    RowLoader<E> al{a, K};
+    return launch_gemm<Cfg, E, false>(al, w, K, M, D_, K, epi, s);
+}
+
 template <class E, int D_>
 static hipError_t launch_resid_ln_d(const E *a, const E *w, const float *bias, const float *resid, float *x,
                                     const float *gamma, const float *beta, void *xn, int M, int K, float eps,
                                     hipStream_t s) {
-    typedef GemmCfg<64, D_, 2, 4> Cfg;  // 8 waves, wave tile 32 x D/4
+    typedef GemmCfg<64, D_, 2, 4> Cfg8;  // 8 waves, wave tile 32 x D/4
     EpiResidLN<E, D_> epi{bias, resid, x, gamma, beta, xn, M, eps};
     epi.wt = ((ocm_wt_mask() >> 2) & 1) | ((ocm_wt_mask() >> 4) & 2);  // mask 4: xn, mask 32: x
-    if constexpr (Elem<E>::MODE == 2) {
-        // One 8-wave workgroup per CU: the two-step register prefetch hides more latency than a two-stage LDS-DMA ring
-        // (fc2 + LayerNorm at ViT-S/16, B = 64: 72 us against 89 us), and a third stage does not fit next to the
-        // 96 KiB epilogue image. Knob 4 = 2 forces the DMA loop (development A/B).
 #ifdef OCM_DEV
-        if (OCM_KNOB(4) == 2) {
-            if (K % Elem<E>::KROW) return hipErrorInvalidValue;
-            switch (K / Elem<E>::KROW) {
-                case 12: return launch_gemm_dma_ks<Cfg, E, 12, 2>(a, K, w, K, M, D_, K, epi, s);
-                case 48: return launch_gemm_dma_ks<Cfg, E, 48, 2>(a, K, w, K, M, D_, K, epi, s);
-                default: return launch_gemm_dma_ks<Cfg, E, 0, 2>(a, K, w, K, M, D_, K, epi, s);
-            }
-        }
-#endif
+    if constexpr (Elem<E>::MODE == 2) {
+        // development A/B (knob 4): 2 = the 8-wave tile on the two-stage LDS-DMA loop
+        if (OCM_KNOB(4) == 2) return launch_resid_ln_cfg<Cfg8, E, D_>(2, a, w, epi, M, K, s);
     }
-    RowLoader<E> al{a, K};
-    return launch_gemm<Cfg, E, false>(al, w, K, M, D_, K, epi, s);
+#endif
+    // One 8-wave workgroup per CU on the register-staged loop (two-step prefetch of both operands)
+    return launch_resid_ln_cfg<Cfg8, E, D_>(0, a, w, epi, M, K, s);
 }
 
 template <class E>
@@ -446,11 +619,16 @@ struct EpiQK {
     float *qkv32;  // optional (3,B,H,N,hd) fp32, or nullptr
     int M, ntok, npad, H, D, B, hd;
     int wt = 0;  // write-through stores for q / k
+    LnFold ln;   // norm1 folded into this projection (the accumulator then starts at 0)
+    static constexpr bool ROWTAB = true;
+    __device__ __forceinline__ void row_raw(int m, f32x2 (&raw)[EPI_MAXS]) const { ln_row_raw(ln, m, raw); }
+    __device__ __forceinline__ f32x2 row_final(const f32x2 (&raw)[EPI_MAXS]) const { return ln_row_final(ln, raw); }
+    __device__ __forceinline__ f32x2 col_entry(int n) const { return ln_col_entry(ln, n); }
     // C is [BM][BN] (rows = tokens). One lane moves 8 consecutive head-dim columns of one token. A lane keeps its
     // column chunk for the whole tile and walks the rows in constant steps, so which / head / d are computed once
     // and (image b, token t) advance incrementally: no integer division per chunk.
     template <class Cfg>
-    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
+    __device__ __forceinline__ void run(const float *C, int m0, int n0, const f32x2 *rowtab, const f32x2 *coltab) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, CPR = BN / 8;
         static_assert(NT % CPR == 0 && BM % (NT / CPR) == 0, "a lane keeps one column chunk");
         constexpr int RSTEP = NT / CPR, ITERS = BM / RSTEP;
@@ -461,12 +639,24 @@ struct EpiQK {
         int m = m0 + row0;
         int b = m / ntok, t = m - b * ntok;
         E *base = which ? k : q;
+        f32x2 cd[8];  // (c, d) of this lane's eight columns
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cd[e] = ln.stats ? coltab[col + e] : f32x2{0.f, 0.f};
 #pragma unroll 4
         for (int i = 0; i < ITERS; ++i) {
             if (m >= M) break;
             const int row = row0 + i * RSTEP;
-            const f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
-            const f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4);
+            f32x4 v0 = *(const f32x4 *)(C + row * BN + col);
+            f32x4 v1 = *(const f32x4 *)(C + row * BN + col + 4);
+            if (ln.stats) {
+                const f32x2 mr = rowtab[row];
+                const float mu = mr[0], rstd = mr[1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v0[e] = fmaf(rstd, fmaf(-mu, cd[e][0], v0[e]), cd[e][1]);
+                    v1[e] = fmaf(rstd, fmaf(-mu, cd[4 + e][0], v1[e]), cd[4 + e][1]);
+                }
+            }
             if (base) {
                 char *rowp = (char *)base + ((int64_t)(b * H + head) * npad + t) * 64 * (int)sizeof(E);
                 if (Elem<E>::EPW == 8) {
@@ -501,11 +691,16 @@ struct EpiVt {
     float *qkv32;
     int M, ntok, npad, H, D, B, hd;
     bool want_v;  // compute the V third at all
+    LnFold ln;
+    static constexpr bool ROWTAB = true;
+    __device__ __forceinline__ void row_raw(int m, f32x2 (&raw)[EPI_MAXS]) const { ln_row_raw(ln, m, raw); }
+    __device__ __forceinline__ f32x2 row_final(const f32x2 (&raw)[EPI_MAXS]) const { return ln_row_final(ln, raw); }
+    __device__ __forceinline__ f32x2 col_entry(int n) const { return ln_col_entry(ln, n); }
     // C is the TRANSPOSED tile [BN][BM] (rows = features n, columns = tokens m). Consecutive lanes
     // take consecutive tokens of one feature row, so each store instruction writes contiguous runs
     // of V^T (vt[(b*H+head)][d][t], t contiguous).
     template <class Cfg>
-    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
+    __device__ __forceinline__ void run(const float *C, int m0, int n0, const f32x2 *rowtab, const f32x2 *coltab) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
         constexpr int RS = NT >= BM ? NT / BM : 1;  // feature rows handled per sweep
         static_assert(NT >= BM, "one lane per token column");
@@ -514,11 +709,17 @@ struct EpiVt {
         if (m >= M) return;
         const int b = m / ntok, t = m - b * ntok;
         const int rem0 = n0 - 2 * D;
+        const f32x2 mr = rowtab[col];  // (0, 1) without a folded LayerNorm
+        const float mu = mr[0], rstd = mr[1];
 #pragma unroll 4
         for (int row = threadIdx.x / BM; row < BN; row += RS) {
             const int rem = rem0 + row;
             const int head = hd == 64 ? rem >> 6 : rem / hd, d = rem - head * hd;  // no integer division on the hot path
-            const float v = C[row * BM + col];
+            float v = C[row * BM + col];
+            if (ln.stats) {
+                const f32x2 cd = coltab[row];
+                v = fmaf(rstd, fmaf(-mu, cd[0], v), cd[1]);
+            }
             if (vt) store_act1((E *)nullptr, (char *)vt + ((int64_t)(b * H + head) * 64 + d) * npad * (int)sizeof(E), t, v);
             if (qkv32) qkv32[((((int64_t)2 * B + b) * H + head) * ntok + t) * hd + d] = v;
         }
@@ -537,12 +738,13 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader<E> al, const E *
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
+    const EpiPre pre = epi_prefetch<Cfg>(eqk, m0, n0, M, N);
     if (n0 < 2 * D) {  // workgroup-uniform
         gemm_mainloop<Cfg, E, false, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
-        run_epilogue<Cfg, false>(acc, smem, eqk, m0, n0);
+        run_epilogue<Cfg, false>(acc, smem, eqk, m0, n0, true, &pre);
     } else {
         gemm_mainloop<Cfg, E, true, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
-        run_epilogue<Cfg, true>(acc, smem, ev, m0, n0);
+        run_epilogue<Cfg, true>(acc, smem, ev, m0, n0, true, &pre);
     }
 }
 
@@ -557,12 +759,14 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_dma_kernel(const E *__restrict__ 
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
+    const EpiPre pre = epi_prefetch<Cfg>(eqk, m0, n0, M, N);
+    constexpr int RING = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
     if (n0 < 2 * D) {  // workgroup-uniform
         gemm_mainloop_dma<Cfg, E, false, KSTEPS, NSTAGE>(A, K, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
-        run_epilogue<Cfg, false>(acc, smem, eqk, m0, n0);
+        run_epilogue<Cfg, false, EpiQK<E>, RING>(acc, smem, eqk, m0, n0, true, &pre);
     } else {
         gemm_mainloop_dma<Cfg, E, true, KSTEPS, NSTAGE>(A, K, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
-        run_epilogue<Cfg, true>(acc, smem, ev, m0, n0);
+        run_epilogue<Cfg, true, EpiVt<E>, RING>(acc, smem, ev, m0, n0, true, &pre);
     }
 }
 
@@ -570,7 +774,7 @@ template <class Cfg, class E, int KSTEPS, int NSTAGE>
 static hipError_t launch_qkv_dma_ks(const E *a, const E *w, int M, int D, const EpiQK<E> &eqk, const EpiVt<E> &ev,
                                     hipStream_t s) {
     auto kern = qkv_dma_kernel<Cfg, E, KSTEPS, NSTAGE>;
-    constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
+    constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128 + (Cfg::BM + Cfg::BN) * 8;  // + the epilogues' row / column tables
     static unsigned long long optin = 0;
     if (hipError_t e = ensure_lds_optin((const void *)kern, LDS, optin); e != hipSuccess) return e;
     const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((ev.want_v ? 3 : 2) * D / Cfg::BN);
@@ -593,10 +797,11 @@ template <class Cfg, class E, int KSTEPS>
 static hipError_t launch_qkv_ks(const RowLoader<E> &al, const E *w, int M, int D, const EpiQK<E> &eqk,
                                 const EpiVt<E> &ev, hipStream_t s) {
     auto kern = qkv_kernel<Cfg, E, KSTEPS>;
+    constexpr int LDS = Cfg::LDS_BYTES + (Cfg::BM + Cfg::BN) * 8;  // + the epilogues' row / column tables
     static unsigned long long optin = 0;
-    if (hipError_t e = ensure_lds_optin((const void *)kern, Cfg::LDS_BYTES, optin); e != hipSuccess) return e;
+    if (hipError_t e = ensure_lds_optin((const void *)kern, LDS, optin); e != hipSuccess) return e;
     const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * ((ev.want_v ? 3 : 2) * D / Cfg::BN);
-    kern<<<dim3(tiles), dim3(Cfg::NT), Cfg::LDS_BYTES, s>>>(al, w, M, D, eqk, ev);
+    kern<<<dim3(tiles), dim3(Cfg::NT), LDS, s>>>(al, w, M, D, eqk, ev);
     return hipGetLastError();
 }
 
@@ -614,7 +819,8 @@ static hipError_t launch_qkv_cfg(const RowLoader<E> &al, const E *w, int M, int 
 
 template <class E>
 hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E *vt, float *qkv_f32, int batch,
-                               int n_tokens, int n_pad, int heads, int head_dim, bool want_v, hipStream_t s) {
+                               int n_tokens, int n_pad, int heads, int head_dim, bool want_v, hipStream_t s,
+                               const LnFold &ln) {
     const int D = heads * head_dim, M = batch * n_tokens;
     if (head_dim != 64 && (q || k || vt)) return hipErrorInvalidValue;  // operand copies exist for 64-channel heads only
     if (head_dim % 8) return hipErrorInvalidValue;                      // a lane's 8 columns stay inside one head
@@ -622,6 +828,12 @@ hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E
     EpiQK<E> eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch, head_dim};
     eqk.wt = (ocm_wt_mask() >> 1) & 1;
     EpiVt<E> ev{bias, vt, qkv_f32, M, n_tokens, n_pad, heads, D, batch, head_dim, want_v};
+    if (ln.stats) {  // folded norm1: the bias travels in ln.d, the accumulators start at zero
+        eqk.ln = ev.ln = ln;
+        eqk.bias = ev.bias = nullptr;
+        if (OCM_KNOB(6) == 1) eqk.ln.stats = ev.ln.stats = nullptr;  // development timing probe (wrong results)
+        if (OCM_KNOB(6) == 2) eqk.ln.nslot = ev.ln.nslot = 1;
+    }
     if constexpr (Elem<E>::MODE == 0)
         if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_cfg<Cfg256x256, E>(al, w, M, D, eqk, ev, s);
     const long t128 = (long)((M + 127) / 128) * (3 * D / 128);
@@ -713,38 +925,70 @@ struct PatchLoader {
 // With a SimMIM mask (model.py:28-33) the patch row is first blended with the mask token:
 // acc*(1-w) + mask_token*w, w = mask[b][pi], evaluated in that order in fp32.
 struct EpiPatch {
+    static constexpr bool ROWTAB = false;
     const float *bias, *pos;
     float *x;
     int M, P, ntok, D;
     const float *mask, *mask_tok;
+    StatsOut so;  // split pairs + row sums of the token rows (the first LayerNorm folded into the first qkv projection)
     template <class Cfg>
-    __device__ __forceinline__ void run(const float *C, int m0, int n0) const {
+    __device__ __forceinline__ void run(const float *C, int m0, int n0, const f32x2 *rowtab, const f32x2 *coltab) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, CPR = BN / 4;
+        static_assert((BM * CPR) % NT == 0 && CPR <= 32 && (CPR & (CPR - 1)) == 0, "CPR lanes of one wave half own a row");
 #pragma unroll 4
         for (int q = threadIdx.x; q < BM * CPR; q += NT) {
             const int row = q / CPR, col = (q - row * CPR) * 4;
             const int m = m0 + row, n = n0 + col;
-            if (m >= M || n >= D) continue;
-            const int b = m / P, t = m - b * P;
+            const bool ok = m < M && n < D;
+            const int mc = min(m, M - 1), nc = min(n, D - 4);
+            const int b = mc / P, t = mc - b * P;
             f32x4 v = *(const f32x4 *)(C + row * BN + col);
             if (mask) {
-                const float w = mask[m], omw = 1.0f - w;
-                const f32x4 tk = *(const f32x4 *)(mask_tok + n);
+                const float w = mask[mc], omw = 1.0f - w;
+                const f32x4 tk = *(const f32x4 *)(mask_tok + nc);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] * omw + tk[e] * w;  // exact for the 0/1 masks SimMIM draws
             }
-            v += *(const f32x4 *)(pos + (int64_t)(1 + t) * D + n);
-            *(f32x4 *)(x + ((int64_t)b * ntok + 1 + t) * D + n) = v;
+            v += *(const f32x4 *)(pos + (int64_t)(1 + t) * D + nc);
+            const int64_t xrow = (int64_t)b * ntok + 1 + t;
+            if (ok) *(f32x4 *)(x + xrow * D + n) = v;
+            if (so.stats) {  // wave-uniform
+                float s1 = 0.f, s2 = 0.f;
+                if (ok) {
+                    bf16x4 hi, lo;
+                    split4(v, hi, lo);
+                    char *g = (char *)so.xs + xrow * D * 4 + sp_off(n);
+                    *(bf16x4 *)g = hi;
+                    *(bf16x4 *)(g + 64) = lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1 += v[e];
+                        s2 = fmaf(v[e], v[e], s2);
+                    }
+                }
+#pragma unroll
+                for (int o = CPR / 2; o > 0; o >>= 1) {
+                    s1 += __shfl_xor(s1, o, 64);
+                    s2 += __shfl_xor(s2, o, 64);
+                }
+                const int sl = threadIdx.x & (CPR - 1);
+                if (ok && sl < BN / 64) {  // m < M; the tile's BN / 64 slots of the row (n0 + 64 sl < D by D % 64 == 0 ... checked below)
+                    if (n0 + 64 * sl < D) {
+                        const f32x2 val = {sl ? 0.f : s1, sl ? 0.f : s2};
+                        *((f32x2 *)so.stats + xrow * (D >> 6) + (n0 >> 6) + sl) = val;
+                    }
+                }
+            }
         }
     }
 };
 
 template <class E>
 hipError_t launch_patch_e(const PatchArgs &pa, const E *w, const float *bias, const float *pos, float *x, int dim,
-                                 hipStream_t s) {
+                                 hipStream_t s, const StatsOut &so) {
     const int P = pa.hp * pa.wp, M = pa.batch * P, K = pa.chans * pa.p * pa.p;
     PatchLoader<E> al{pa.image, pa.sb, pa.sc, pa.sy, pa.origins, P, pa.wp, pa.p, pa.p * pa.p};
-    EpiPatch epi{bias, pos, x, M, P, P + 1, dim, pa.mask, pa.mask_tok};
+    EpiPatch epi{bias, pos, x, M, P, P + 1, dim, pa.mask, pa.mask_tok, so};
     if (dim % 128 == 0 && M > 64) return launch_gemm<Cfg64x128, E, false>(al, w, K, M, dim, K, epi, s);
     return launch_gemm<Cfg64x64, E, false>(al, w, K, M, dim, K, epi, s);
 }

@@ -7,7 +7,7 @@
 // entry templates of gemm_kernels.h (defined and explicitly instantiated in kernels_gemm_inst.hip)
 template <class E>
 hipError_t launch_linear_e(const E *a, const E *w, const float *bias, const float *resid, void *out, int M, int N, int K,
-                           int epilogue, hipStream_t s);
+                           int epilogue, hipStream_t s, const LnFold &ln, const StatsOut &so);
 template <class E>
 hipError_t launch_linear_ld_e(const E *a, int64_t lda, const E *w, const float *bias, const float *resid, void *out,
                               int64_t ldo, int M, int N, int K, int epilogue, hipStream_t s);
@@ -16,10 +16,10 @@ hipError_t launch_resid_ln_e(const E *a, const E *w, const float *bias, const fl
                              const float *beta, void *xn, int M, int D, int K, float eps, hipStream_t s);
 template <class E>
 hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E *vt, float *qkv_f32, int batch,
-                        int n_tokens, int n_pad, int heads, int head_dim, bool want_v, hipStream_t s);
+                        int n_tokens, int n_pad, int heads, int head_dim, bool want_v, hipStream_t s, const LnFold &ln);
 template <class E>
 hipError_t launch_patch_e(const PatchArgs &pa, const E *w, const float *bias, const float *pos, float *x, int dim,
-                          hipStream_t s);
+                          hipStream_t s, const StatsOut &so);
 
 #ifdef OCM_DEV  // development build only (dev_knobs.h)
 int g_ocm_knobs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -42,10 +42,10 @@ hipError_t launch_linear_ld(int prec, const void *a, int64_t lda, const void *w,
 }
 
 hipError_t launch_linear(int prec, const void *a, const void *w, const float *bias, const float *resid, void *out, int M,
-                         int N, int K, int epilogue, hipStream_t s) {
-    if (prec == 2) return launch_linear_e<sp32>((const sp32 *)a, (const sp32 *)w, bias, resid, out, M, N, K, epilogue, s);
-    if (prec) return launch_linear_e<float>((const float *)a, (const float *)w, bias, resid, out, M, N, K, epilogue, s);
-    return launch_linear_e<bf16>((const bf16 *)a, (const bf16 *)w, bias, resid, out, M, N, K, epilogue, s);
+                         int N, int K, int epilogue, hipStream_t s, const LnFold &ln, const StatsOut &so) {
+    if (prec == 2) return launch_linear_e<sp32>((const sp32 *)a, (const sp32 *)w, bias, resid, out, M, N, K, epilogue, s, ln, so);
+    if (prec) return launch_linear_e<float>((const float *)a, (const float *)w, bias, resid, out, M, N, K, epilogue, s, ln, so);
+    return launch_linear_e<bf16>((const bf16 *)a, (const bf16 *)w, bias, resid, out, M, N, K, epilogue, s, ln, so);
 }
 
 // D = 512 is not offered: its split-bf16 instantiation needs more than 256 registers per lane (scratch spills)
@@ -64,21 +64,21 @@ hipError_t launch_linear_resid_ln(int prec, const void *a, const void *w, const 
 
 hipError_t launch_qkv(int prec, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
                       float *qkv_f32, int batch, int n_tokens, int n_pad, int heads, int head_dim, bool want_v,
-                      hipStream_t s) {
+                      hipStream_t s, const LnFold &ln) {
     if (prec == 2)
         return launch_qkv_e<sp32>((const sp32 *)a, (const sp32 *)w, bias, (sp32 *)q, (sp32 *)k, (sp32 *)vt, qkv_f32, batch,
-                                  n_tokens, n_pad, heads, head_dim, want_v, s);
+                                  n_tokens, n_pad, heads, head_dim, want_v, s, ln);
     if (prec)
         return launch_qkv_e<float>((const float *)a, (const float *)w, bias, (float *)q, (float *)k, (float *)vt, qkv_f32,
-                                   batch, n_tokens, n_pad, heads, head_dim, want_v, s);
+                                   batch, n_tokens, n_pad, heads, head_dim, want_v, s, ln);
     return launch_qkv_e<bf16>((const bf16 *)a, (const bf16 *)w, bias, (bf16 *)q, (bf16 *)k, (bf16 *)vt, qkv_f32, batch,
-                              n_tokens, n_pad, heads, head_dim, want_v, s);
+                              n_tokens, n_pad, heads, head_dim, want_v, s, ln);
 }
 
 hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, const float *bias, const float *pos,
-                              float *x, int dim, hipStream_t s) {
-    if (prec == 2) return launch_patch_e<sp32>(pa, (const sp32 *)w, bias, pos, x, dim, s);
-    if (prec) return launch_patch_e<float>(pa, (const float *)w, bias, pos, x, dim, s);
-    return launch_patch_e<bf16>(pa, (const bf16 *)w, bias, pos, x, dim, s);
+                              float *x, int dim, hipStream_t s, const StatsOut &so) {
+    if (prec == 2) return launch_patch_e<sp32>(pa, (const sp32 *)w, bias, pos, x, dim, s, so);
+    if (prec) return launch_patch_e<float>(pa, (const float *)w, bias, pos, x, dim, s, so);
+    return launch_patch_e<bf16>(pa, (const bf16 *)w, bias, pos, x, dim, s, so);
 }
 

@@ -12,8 +12,17 @@ typedef sp32 InstE;
 #endif
 
 #if OCM_INST_PART == 0
+#if defined(OCM_GEMM_STAMPS) && OCM_INST_E == 2
+// development only: the cycle stamps of THIS translation unit's kernels (nn.Linear, split-bf16); g_stamps is per object
+extern "C" int ocm_debug_stamps_linear(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), (size_t)n * 8);
+}
+extern "C" int ocm_debug_wstamps_linear(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wstamps), (size_t)n * 8);
+}
+#endif
 template hipError_t launch_linear_e<InstE>(const InstE *, const InstE *, const float *, const float *, void *, int, int, int,
-                                           int, hipStream_t);
+                                           int, hipStream_t, const LnFold &, const StatsOut &);
 #if OCM_INST_E != 2  // the strided launcher serves Swin (bf16 / fp32 only)
 template hipError_t launch_linear_ld_e<InstE>(const InstE *, int64_t, const InstE *, const float *, const float *, void *,
                                               int64_t, int, int, int, int, hipStream_t);
@@ -22,9 +31,9 @@ template hipError_t launch_linear_ld_e<InstE>(const InstE *, int64_t, const Inst
 template hipError_t launch_resid_ln_e<InstE>(const InstE *, const InstE *, const float *, const float *, float *,
                                              const float *, const float *, void *, int, int, int, float, hipStream_t);
 template hipError_t launch_qkv_e<InstE>(const InstE *, const InstE *, const float *, InstE *, InstE *, InstE *, float *, int,
-                                        int, int, int, int, bool, hipStream_t);
+                                        int, int, int, int, bool, hipStream_t, const LnFold &);
 template hipError_t launch_patch_e<InstE>(const PatchArgs &, const InstE *, const float *, const float *, float *, int,
-                                          hipStream_t);
+                                          hipStream_t, const StatsOut &);
 #if defined(OCM_GEMM_STAMPS) && OCM_INST_E == 2
 // development only: workgroups per CU the runtime grants a few of the shipped kernels (tools/stamps_x3.py)
 extern "C" int ocm_debug_occupancy(int *out, int n) {

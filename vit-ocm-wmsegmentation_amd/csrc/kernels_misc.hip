@@ -300,6 +300,84 @@ hipError_t launch_cls_rows(const float *cls, const float *pos, float *x, int bat
     return hipGetLastError();
 }
 
+// ---- LayerNorm folded into the GEMM that consumes it (split-bf16 forward) ----
+// The residual stream x is handed to the next GEMM UN-normalised, as split pairs, next to per-row sums (S1 = sum x,
+// S2 = sum x^2, accumulated by the producing epilogues); the consumer multiplies by W' = W * gamma and finishes
+//   LN(x) W^T + b = rstd * (x W'^T - mu * c) + d,   c[n] = sum_k W'[n][k],   d[n] = sum_k beta[k] W[n][k] + b[n]
+// in its epilogue. The cls row of every image (prepare_tokens :203-207) is produced here with its sums (one wavefront per
+// image; the patch rows come from the patch-embedding epilogue).
+__global__ __launch_bounds__(64) void cls_rows_stats_kernel(const float *__restrict__ cls, const float *__restrict__ pos,
+                                                            float *__restrict__ x, char *__restrict__ xs,
+                                                            float *__restrict__ stats, int n_tokens, int dim) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const size_t row = (size_t)b * n_tokens;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < dim; c += 64) {
+        const float v = cls[c] + pos[c];
+        x[row * dim + c] = v;
+        bf16 hi, lo;
+        split1(v, hi, lo);
+        char *g = xs + row * dim * 4 + sp_off(c);
+        *(bf16 *)g = hi;
+        *(bf16 *)(g + 64) = lo;
+        s1 += v;
+        s2 = fmaf(v, v, s2);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    const int nslot = dim >> 6;  // slot 0 carries the sums of the whole row, the others zeros (launch.h: LnFold)
+    if (lane < nslot) {
+        stats[(row * nslot + lane) * 2] = lane ? 0.f : s1;
+        stats[(row * nslot + lane) * 2 + 1] = lane ? 0.f : s2;
+    }
+}
+
+hipError_t launch_cls_rows_stats(const float *cls, const float *pos, float *x, void *xs, float *stats, int batch,
+                                 int n_tokens, int dim, hipStream_t s) {
+    cls_rows_stats_kernel<<<dim3(batch), dim3(64), 0, s>>>(cls, pos, x, (char *)xs, stats, n_tokens, dim);
+    return hipGetLastError();
+}
+
+// W (N, K) fp32, gamma / beta (K), bias (N) -> W' = W * gamma as split pairs, c (N), d (N). One wavefront per output row;
+// the two row sums in float64 (they multiply O(1) row statistics in every epilogue).
+__global__ __launch_bounds__(64) void fold_ln_kernel(const float *__restrict__ W, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, const float *__restrict__ bias,
+                                                     char *__restrict__ Wf, float *__restrict__ cvec,
+                                                     float *__restrict__ dvec, int K) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const float *w = W + (size_t)n * K;
+    char *dst = Wf + (size_t)n * K * 4;
+    double c = 0.0, d = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const float wg = w[k] * gamma[k];
+        bf16 hi, lo;
+        split1(wg, hi, lo);
+        *(bf16 *)(dst + sp_off(k)) = hi;
+        *(bf16 *)(dst + sp_off(k) + 64) = lo;
+        c += (double)wg;
+        d += (double)beta[k] * (double)w[k];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c += __shfl_xor(c, o, 64);
+        d += __shfl_xor(d, o, 64);
+    }
+    if (lane == 0) {
+        cvec[n] = (float)c;
+        dvec[n] = (float)(d + (double)(bias ? bias[n] : 0.f));
+    }
+}
+
+hipError_t launch_fold_ln(const float *W, const float *gamma, const float *beta, const float *bias, void *Wf, float *cvec,
+                          float *dvec, int N, int K, hipStream_t s) {
+    if (K % 32) return hipErrorInvalidValue;
+    fold_ln_kernel<<<dim3(N), dim3(64), 0, s>>>(W, gamma, beta, bias, (char *)Wf, cvec, dvec, K);
+    return hipGetLastError();
+}
+
 // ---- encoders of model.py:48-53,134-139: x[:, 1:].permute(0, 2, 1).reshape(B, C, H, W) ----
 // y: (B, N, D) normed tokens; out: (B, D, N-1). 32x32 tiles through LDS so that both sides are coalesced.
 __global__ __launch_bounds__(256) void tokens_to_fmap_kernel(const float *__restrict__ y, float *__restrict__ out,

@@ -18,13 +18,36 @@ hipError_t launch_fold_f32(const float *src, float *dst, int D, int C, int pp, h
 hipError_t launch_im2col3x3(int prec, const float *in, void *out, int batch, int h, int w, int C, int relu, hipStream_t s);
 hipError_t launch_cls_rows(const float *cls, const float *pos, float *x, int batch, int n_tokens, int dim,
                            hipStream_t s);
+// ---- LayerNorm folded into its consumer GEMM (split-bf16 forward) ----
+// What a consuming epilogue needs to finish LN(x) W^T + b from the raw products acc = x W'^T (W' = W * gamma):
+//   out = rstd * (acc - mu * c) + d,  mu = S1 / dim, rstd = 1 / sqrt(S2 / dim - mu^2 + eps)
+// The sums of a row live in dim / 64 slots, one per 64 columns: a producing tile writes (sum, sum of squares) over ITS
+// columns into its first slot and zeros into the other slots it covers, the consumer adds the slots in index order. Every
+// slot is written exactly once per layer, so nothing is zeroed beforehand and no atomics are involved: the statistics —
+// and with them every output — are the same bits from run to run, whatever the tile shapes on either side.
+struct LnFold {
+    const float *stats = nullptr;  // [rows][dim / 64][2] of the consumer's A rows, or null: no folding
+    const float *c = nullptr, *d = nullptr;  // per output column
+    float inv_dim = 0.f, eps = 0.f;
+    int nslot = 0;  // dim / 64
+};
+// What a producing epilogue (x = resid + acc) writes besides x when the next LayerNorm is folded
+struct StatsOut {
+    void *xs = nullptr;      // [rows][N] split pairs of x, or null
+    float *stats = nullptr;  // [rows][N / 64][2]
+};
+hipError_t launch_cls_rows_stats(const float *cls, const float *pos, float *x, void *xs, float *stats, int batch,
+                                 int n_tokens, int dim, hipStream_t s);
+hipError_t launch_fold_ln(const float *W, const float *gamma, const float *beta, const float *bias, void *Wf, float *cvec,
+                          float *dvec, int N, int K, hipStream_t s);
 
 // `prec` selects the operand element type of the contraction kernels: 0 = bf16 (OCM_PREC_BF16),
 // 1 = fp32 (OCM_PREC_FP32), 2 = split-bf16 pairs (OCM_PREC_BF16X3, common.h: sp32). Activation buffers
 // (a, q, k, vt, ctx, ...) and weights are of that type.
 // ---- kernels_gemm.hip
 hipError_t launch_linear(int prec, const void *a, const void *w, const float *bias, const float *resid, void *out, int M,
-                         int N, int K, int epilogue, hipStream_t s);
+                         int N, int K, int epilogue, hipStream_t s, const LnFold &ln = LnFold(),
+                         const StatsOut &so = StatsOut());
 // head_dim 64: q / k / vt are the attention kernels' operand copies (vt may be null when V is never read: want_v
 // false skips the V third). Any other head_dim (multiple of 8): q = k = vt = null, qkv_f32 (3,B,H,N,hd) is the output.
 // proj / fc2 + residual fused with the LayerNorm that follows (full-row tiles, D in {128, 256, 384})
@@ -34,7 +57,7 @@ hipError_t launch_linear_resid_ln(int prec, const void *a, const void *w, const 
                                   hipStream_t s);
 hipError_t launch_qkv(int prec, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
                       float *qkv_f32, int batch, int n_tokens, int n_pad, int heads, int head_dim, bool want_v,
-                      hipStream_t s);
+                      hipStream_t s, const LnFold &ln = LnFold());
 // Attention for heads that are not 64 wide (model.py:96-97: 3 heads x 128): fp32 FMA arithmetic on the fp32 qkv tensor.
 // ctx (activation type of `prec`, [B*N][H*hd]) / attn (B,H,N,N) / rows (B,H,n_rows,N-1) are optional outputs.
 hipError_t launch_attention_generic(int prec, const float *qkv, void *ctx, float *attn, const int32_t *query_rows,
@@ -49,7 +72,7 @@ struct PatchArgs {
     const float *mask_tok = nullptr;  // [D]
 };
 hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, const float *bias, const float *pos,
-                              float *x, int dim, hipStream_t s);
+                              float *x, int dim, hipStream_t s, const StatsOut &so = StatsOut());
 
 // ---- kernels_attn.hip
 hipError_t launch_attention(int prec, const void *q, const void *k, const void *vt, void *ctx, float *lse2, int batch,

@@ -82,6 +82,10 @@ class Engine:
             check(self.lib.ocm_vit_create(C.byref(self.cfg), C.byref(self._h)))
         self._ws = {}
         self.hip_graph = {"1": True, "auto": "auto"}.get(os.environ.get("OCM_HIP_GRAPH", "0"), False)
+        if os.environ.get("OCM_FUSE_LN"):  # "auto" / "never" / "always" (A/B runs; the default is "auto")
+            self.set_fuse_layernorm(os.environ["OCM_FUSE_LN"])
+        if os.environ.get("OCM_FOLD_LN"):  # "0" switches the folded LayerNorm off (A/B runs)
+            self.set_fold_layernorm(os.environ["OCM_FOLD_LN"] != "0")
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -196,6 +200,12 @@ class Engine:
         embedding width has the full-row GEMM + LayerNorm kernel). All three give bit-identical results."""
         value = {"auto": 0, "never": 1, "always": 2}[mode]
         check(self.lib.ocm_vit_set_option(self._h, _lib.OCM_OPT_FUSE_LN, value))
+
+    def set_fold_layernorm(self, on):
+        """Per-handle option OCM_OPT_FOLD_LN (split-bf16 engines): True (default) hands the residual stream to the qkv / fc1
+        GEMMs un-normalised and finishes the LayerNorm in their epilogues; False runs LayerNorm kernels (or the fused
+        GEMM + LayerNorm kernels, see set_fuse_layernorm)."""
+        check(self.lib.ocm_vit_set_option(self._h, _lib.OCM_OPT_FOLD_LN, 0 if on else 1))
 
     def graph_stats(self):
         """(replays, captures) of the hipGraph path."""
