@@ -538,23 +538,26 @@ struct EpiPre {
     f32x2 raw[EPI_MAXS];
     f32x2 cd;
 };
+struct EpiNoPre {};  // epilogues without tables carry nothing across the main loop
 template <class Cfg, class Epi>
-__device__ __forceinline__ EpiPre epi_prefetch(const Epi &epi, int m0, int n0, int M, int N) {
-    EpiPre p;
-#pragma unroll
-    for (int i = 0; i < EPI_MAXS; ++i) p.raw[i] = f32x2{0.f, 0.f};
-    p.cd = f32x2{0.f, 0.f};
+__device__ __forceinline__ auto epi_prefetch(const Epi &epi, int m0, int n0, int M, int N) {
     if constexpr (Epi::ROWTAB) {
+        EpiPre p;
+#pragma unroll
+        for (int i = 0; i < EPI_MAXS; ++i) p.raw[i] = f32x2{0.f, 0.f};
+        p.cd = f32x2{0.f, 0.f};
         if (threadIdx.x < Cfg::BM) epi.row_raw(min(m0 + (int)threadIdx.x, M - 1), p.raw);
         if (threadIdx.x < Cfg::BN) p.cd = epi.col_entry(min(n0 + (int)threadIdx.x, N - 1));
+        return p;
+    } else {
+        return EpiNoPre();
     }
-    return p;
 }
 
 // LDS_AVAIL: bytes of LDS the kernel owns (the register-staged kernels: Cfg::LDS_BYTES; the LDS-DMA kernels: their ring)
-template <class Cfg, bool SWAP, class Epi, int LDS_AVAIL = Cfg::LDS_BYTES>
+template <class Cfg, bool SWAP, class Epi, int LDS_AVAIL = Cfg::LDS_BYTES, class Pre = EpiNoPre>
 __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::TN], char *smem, const Epi &epi, int m0,
-                                             int n0, bool active = true, const EpiPre *pre = nullptr) {
+                                             int n0, bool active = true, const Pre *pre = nullptr) {
     f32x2 *rowtab = (f32x2 *)(smem + LDS_AVAIL), *coltab = rowtab + Cfg::BM;
     if constexpr (Epi::ROWTAB) {
         if (threadIdx.x < Cfg::BM) rowtab[threadIdx.x] = epi.row_final(pre->raw);
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_dma_kernel(const E *__restrict__
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
-    const EpiPre pre = epi_prefetch<Cfg>(epi, m0, n0, M, N);
+    const auto pre = epi_prefetch<Cfg>(epi, m0, n0, M, N);
     STAMP(0);
 #if defined(OCM_ABL) && OCM_ABL == 4  // ablation 4: epilogue only
 #pragma unroll
@@ -651,7 +654,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_dma_kernel(const E *__restrict__
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-    run_epilogue<Cfg, SWAP, Epi, NSTAGE * (Cfg::BM + Cfg::BN) * 128>(acc, smem, epi, m0, n0, true, &pre);
+    run_epilogue<Cfg, SWAP, Epi, NSTAGE * (Cfg::BM + Cfg::BN) * 128, decltype(pre)>(acc, smem, epi, m0, n0, true, &pre);
 #endif
     STAMP(4);
 #ifdef OCM_GEMM_STAMPS
@@ -671,11 +674,11 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const E *__rest
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
-    const EpiPre pre = epi_prefetch<Cfg>(epi, m0, n0, M, N);
+    const auto pre = epi_prefetch<Cfg>(epi, m0, n0, M, N);
     STAMP(0);
     gemm_mainloop<Cfg, E, SWAP, KSTEPS>(al, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
     STAMP(1);  // prologue + K loop done
-    run_epilogue<Cfg, SWAP>(acc, smem, epi, m0, n0, true, &pre);  // STAMP 2: accumulators staged, 3: barrier passed
+    run_epilogue<Cfg, SWAP, Epi, Cfg::LDS_BYTES, decltype(pre)>(acc, smem, epi, m0, n0, true, &pre);  // STAMP 2: accumulators staged, 3: barrier passed
     STAMP(4);  // epilogue body issued
 #ifdef OCM_GEMM_STAMPS
     __builtin_amdgcn_s_waitcnt(0);

@@ -738,13 +738,13 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader<E> al, const E *
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
-    const EpiPre pre = epi_prefetch<Cfg>(eqk, m0, n0, M, N);
+    const auto pre = epi_prefetch<Cfg>(eqk, m0, n0, M, N);
     if (n0 < 2 * D) {  // workgroup-uniform
         gemm_mainloop<Cfg, E, false, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
-        run_epilogue<Cfg, false>(acc, smem, eqk, m0, n0, true, &pre);
+        run_epilogue<Cfg, false, EpiQK<E>, Cfg::LDS_BYTES, decltype(pre)>(acc, smem, eqk, m0, n0, true, &pre);
     } else {
         gemm_mainloop<Cfg, E, true, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
-        run_epilogue<Cfg, true>(acc, smem, ev, m0, n0, true, &pre);
+        run_epilogue<Cfg, true, EpiVt<E>, Cfg::LDS_BYTES, decltype(pre)>(acc, smem, ev, m0, n0, true, &pre);
     }
 }
 
@@ -759,14 +759,14 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_dma_kernel(const E *__restrict__ 
     const int tm = id / tiles_n, tn = id - tm * tiles_n;
     const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
     f32x16 acc[Cfg::TM][Cfg::TN];
-    const EpiPre pre = epi_prefetch<Cfg>(eqk, m0, n0, M, N);
+    const auto pre = epi_prefetch<Cfg>(eqk, m0, n0, M, N);
     constexpr int RING = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
     if (n0 < 2 * D) {  // workgroup-uniform
         gemm_mainloop_dma<Cfg, E, false, KSTEPS, NSTAGE>(A, K, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
-        run_epilogue<Cfg, false, EpiQK<E>, RING>(acc, smem, eqk, m0, n0, true, &pre);
+        run_epilogue<Cfg, false, EpiQK<E>, RING, decltype(pre)>(acc, smem, eqk, m0, n0, true, &pre);
     } else {
         gemm_mainloop_dma<Cfg, E, true, KSTEPS, NSTAGE>(A, K, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
-        run_epilogue<Cfg, true, EpiVt<E>, RING>(acc, smem, ev, m0, n0, true, &pre);
+        run_epilogue<Cfg, true, EpiVt<E>, RING, decltype(pre)>(acc, smem, ev, m0, n0, true, &pre);
     }
 }
 
@@ -932,52 +932,69 @@ struct EpiPatch {
     const float *mask, *mask_tok;
     StatsOut so;  // split pairs + row sums of the token rows (the first LayerNorm folded into the first qkv projection)
     template <class Cfg>
-    __device__ __forceinline__ void run(const float *C, int m0, int n0, const f32x2 *rowtab, const f32x2 *coltab) const {
+    __device__ __forceinline__ void run(const float *C, int m0, int n0, const f32x2 *, const f32x2 *) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, CPR = BN / 4;
-        static_assert((BM * CPR) % NT == 0 && CPR <= 32 && (CPR & (CPR - 1)) == 0, "CPR lanes of one wave half own a row");
+        if (so.stats) return run_stats<Cfg>(C, m0, n0);  // workgroup-uniform
 #pragma unroll 4
         for (int q = threadIdx.x; q < BM * CPR; q += NT) {
             const int row = q / CPR, col = (q - row * CPR) * 4;
             const int m = m0 + row, n = n0 + col;
-            const bool ok = m < M && n < D;
-            const int mc = min(m, M - 1), nc = min(n, D - 4);
+            if (m >= M || n >= D) continue;
+            const int b = m / P, t = m - b * P;
+            f32x4 v = *(const f32x4 *)(C + row * BN + col);
+            if (mask) {
+                const float w = mask[m], omw = 1.0f - w;
+                const f32x4 tk = *(const f32x4 *)(mask_tok + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * omw + tk[e] * w;  // exact for the 0/1 masks SimMIM draws
+            }
+            v += *(const f32x4 *)(pos + (int64_t)(1 + t) * D + n);
+            *(f32x4 *)(x + ((int64_t)b * ntok + 1 + t) * D + n) = v;
+        }
+    }
+    // the same rows, also as split pairs, with their sums (the first LayerNorm is folded into the first qkv projection):
+    // the CPR lanes that own a row reduce by shuffles, so every lane runs every iteration (rows past M are masked)
+    template <class Cfg>
+    __device__ __forceinline__ void run_stats(const float *C, int m0, int n0) const {
+        constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, CPR = BN / 4;
+        static_assert((BM * CPR) % NT == 0 && CPR <= 32 && (CPR & (CPR - 1)) == 0, "CPR lanes of one wave half own a row");
+        const int sl = threadIdx.x & (CPR - 1), col = sl * 4, n = n0 + col;  // NT % CPR == 0: a lane keeps its columns
+        const bool nok = n < D;
+        const int nc = min(n, D - 4);
+#pragma unroll 1
+        for (int row = threadIdx.x / CPR; row < BM; row += NT / CPR) {
+            const int m = m0 + row;
+            const bool ok = nok && m < M;
+            const int mc = min(m, M - 1);
             const int b = mc / P, t = mc - b * P;
             f32x4 v = *(const f32x4 *)(C + row * BN + col);
             if (mask) {
                 const float w = mask[mc], omw = 1.0f - w;
                 const f32x4 tk = *(const f32x4 *)(mask_tok + nc);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] * omw + tk[e] * w;  // exact for the 0/1 masks SimMIM draws
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * omw + tk[e] * w;
             }
             v += *(const f32x4 *)(pos + (int64_t)(1 + t) * D + nc);
             const int64_t xrow = (int64_t)b * ntok + 1 + t;
-            if (ok) *(f32x4 *)(x + xrow * D + n) = v;
-            if (so.stats) {  // wave-uniform
-                float s1 = 0.f, s2 = 0.f;
-                if (ok) {
-                    bf16x4 hi, lo;
-                    split4(v, hi, lo);
-                    char *g = (char *)so.xs + xrow * D * 4 + sp_off(n);
-                    *(bf16x4 *)g = hi;
-                    *(bf16x4 *)(g + 64) = lo;
+            float s1 = 0.f, s2 = 0.f;
+            if (ok) {
+                *(f32x4 *)(x + xrow * D + n) = v;
+                bf16x4 hi, lo;
+                split4(v, hi, lo);
+                char *g = (char *)so.xs + xrow * D * 4 + sp_off(n);
+                *(bf16x4 *)g = hi;
+                *(bf16x4 *)(g + 64) = lo;
+                s1 = (v[0] + v[1]) + (v[2] + v[3]);
+                s2 = fmaf(v[0], v[0], fmaf(v[1], v[1], fmaf(v[2], v[2], v[3] * v[3])));
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        s1 += v[e];
-                        s2 = fmaf(v[e], v[e], s2);
-                    }
-                }
-#pragma unroll
-                for (int o = CPR / 2; o > 0; o >>= 1) {
-                    s1 += __shfl_xor(s1, o, 64);
-                    s2 += __shfl_xor(s2, o, 64);
-                }
-                const int sl = threadIdx.x & (CPR - 1);
-                if (ok && sl < BN / 64) {  // m < M; the tile's BN / 64 slots of the row (n0 + 64 sl < D by D % 64 == 0 ... checked below)
-                    if (n0 + 64 * sl < D) {
-                        const f32x2 val = {sl ? 0.f : s1, sl ? 0.f : s2};
-                        *((f32x2 *)so.stats + xrow * (D >> 6) + (n0 >> 6) + sl) = val;
-                    }
-                }
+            for (int o = CPR / 2; o > 0; o >>= 1) {
+                s1 += __shfl_xor(s1, o, 64);
+                s2 += __shfl_xor(s2, o, 64);
+            }
+            if (m < M && sl < BN / 64 && n0 + 64 * sl < D) {  // the tile's slots of the row (launch.h: LnFold)
+                const f32x2 val = {sl ? 0.f : s1, sl ? 0.f : s2};
+                *((f32x2 *)so.stats + xrow * (D >> 6) + (n0 >> 6) + sl) = val;
             }
         }
     }
