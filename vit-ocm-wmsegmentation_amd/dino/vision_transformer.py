@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from ..engine import Engine, _p, _require_hip, _stream
+from ..engine import Engine, _p, _require_hip, _stream, to_operand
 from .utils import trunc_normal_
 
 
@@ -28,26 +28,29 @@ def _f32c(t):
     return t.detach().to(torch.float32).contiguous()
 
 
-class _Bf16Cache:
-    """bf16 copy of an fp32 matrix parameter for the stand-alone operator paths."""
+class _OperandCache:
+    """Operand copy (engine.to_operand: bf16 / fp32 / split-bf16 pairs) of an fp32 matrix parameter for the stand-alone
+    operator paths, rebuilt when the parameter or the precision changes."""
 
     def __init__(self):
         self.key, self.val = None, None
 
-    def get(self, param):
-        key = (param.data_ptr(), param._version, param.device)
+    def get(self, param, prec):
+        key = (param.data_ptr(), param._version, param.device, prec)
         if key != self.key:
-            src = _f32c(param)
-            dst = torch.empty(src.shape, dtype=torch.bfloat16, device=src.device)
-            _lib.check(_lib.load().ocm_op_cast_bf16(_p(src), _p(dst), src.numel(), _stream()))
-            self.key, self.val = key, dst
+            self.key, self.val = key, to_operand(_f32c(param), prec)
         return self.val
 
 
-def _cast_bf16(x32):
-    out = torch.empty(x32.shape, dtype=torch.bfloat16, device=x32.device)
-    _lib.check(_lib.load().ocm_op_cast_bf16(_p(x32), _p(out), x32.numel(), _stream()))
-    return out
+_ACT_DTYPE = {_lib.OCM_PREC_BF16: torch.bfloat16, _lib.OCM_PREC_FP32: torch.float32, _lib.OCM_PREC_BF16X3: torch.int32}
+
+
+def _module_prec(mod):
+    """OCM_PREC_* of a free-standing sub-module: its `precision` attribute ("bf16x3" unless changed)."""
+    name = getattr(mod, "precision", _lib.DEFAULT_PRECISION)
+    if name not in _lib.PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {name!r}")
+    return _lib.PRECISIONS[name]
 
 
 def _bias_or_zeros(linear):
@@ -79,21 +82,23 @@ class Mlp(nn.Module):
         self.act = act_layer()
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
         self.drop = nn.Dropout(drop)
-        self._w = (_Bf16Cache(), _Bf16Cache())
+        self._w = (_OperandCache(), _OperandCache())
 
     def forward(self, x):
+        """Free-standing use (outside a VisionTransformer): the stand-alone operators in this module's `precision`
+        ("bf16x3" by default, like the engine; "bf16" / "fp32")."""
         _require_hip(x, "Mlp input")
-        lib = _lib.load()
+        lib, pc = _lib.load(), _module_prec(self)
         shape = x.shape
         x32 = _f32c(x).reshape(-1, shape[-1])
         rows, hid, out_f = x32.shape[0], self.fc1.out_features, self.fc2.out_features
         with torch.cuda.device(x32.device):
-            a = _cast_bf16(x32)
-            h = torch.empty((rows, hid), dtype=torch.bfloat16, device=x32.device)
-            _lib.check(lib.ocm_op_linear(0, _p(a), _p(self._w[0].get(self.fc1.weight)), _p(_bias_or_zeros(self.fc1)), None,
+            a = to_operand(x32, pc)
+            h = torch.empty((rows, hid), dtype=_ACT_DTYPE[pc], device=x32.device)
+            _lib.check(lib.ocm_op_linear(pc, _p(a), _p(self._w[0].get(self.fc1.weight, pc)), _p(_bias_or_zeros(self.fc1)), None,
                                          _p(h), rows, hid, shape[-1], _lib.OCM_EPI_BIAS_GELU_BF16, _stream()))
             y = torch.empty((rows, out_f), dtype=torch.float32, device=x32.device)
-            _lib.check(lib.ocm_op_linear(0, _p(h), _p(self._w[1].get(self.fc2.weight)), _p(_bias_or_zeros(self.fc2)), None,
+            _lib.check(lib.ocm_op_linear(pc, _p(h), _p(self._w[1].get(self.fc2.weight, pc)), _p(_bias_or_zeros(self.fc2)), None,
                                          _p(y), rows, out_f, hid, _lib.OCM_EPI_BIAS_F32, _stream()))
         return y.reshape(*shape[:-1], out_f)
 
@@ -109,32 +114,35 @@ class Attention(nn.Module):
         self.attn_drop = nn.Dropout(attn_drop)
         self.proj = nn.Linear(dim, dim)
         self.proj_drop = nn.Dropout(proj_drop)
-        self._w = (_Bf16Cache(), _Bf16Cache())
+        self._w = (_OperandCache(), _OperandCache())
 
     def forward(self, x, return_qkv=False):
+        """Free-standing use (outside a VisionTransformer): the stand-alone operators in this module's `precision`
+        ("bf16x3" by default, like the engine; "bf16" / "fp32"). The V^T padding columns are zeroed here: the operators
+        never write them and they are multiplied by exact zeros."""
         _require_hip(x, "Attention input")
-        lib = _lib.load()
+        lib, pc = _lib.load(), _module_prec(self)
         B, N, Cd = x.shape
         H = self.num_heads
         if Cd != H * 64:
             raise ValueError("the HIP attention kernels need head_dim == 64")
         x32 = _f32c(x).reshape(B * N, Cd)
-        dev, npad = x32.device, lib.ocm_n_pad(N)
+        dev, npad, adt = x32.device, lib.ocm_n_pad_prec(pc, N), _ACT_DTYPE[pc]
         with torch.cuda.device(dev):
-            a = _cast_bf16(x32)
-            q = torch.empty((B * H, npad, 64), dtype=torch.bfloat16, device=dev)
+            a = to_operand(x32, pc)
+            q = torch.empty((B * H, npad, 64), dtype=adt, device=dev)
             k = torch.empty_like(q)
-            vt = torch.empty((B * H, 64, npad), dtype=torch.bfloat16, device=dev)
+            vt = torch.zeros((B * H, 64, npad), dtype=adt, device=dev)
             qkv = torch.empty((3, B, H, N, 64), dtype=torch.float32, device=dev)
-            _lib.check(lib.ocm_op_qkv_proj(0, _p(a), _p(self._w[0].get(self.qkv.weight)), _p(_bias_or_zeros(self.qkv)),
+            _lib.check(lib.ocm_op_qkv_proj(pc, _p(a), _p(self._w[0].get(self.qkv.weight, pc)), _p(_bias_or_zeros(self.qkv)),
                                            _p(q), _p(k), _p(vt), _p(qkv), B, N, H, _stream()))
-            ctx = torch.empty((B * N, Cd), dtype=torch.bfloat16, device=dev)
+            ctx = torch.empty((B * N, Cd), dtype=adt, device=dev)
             lse = torch.empty((B * H, N), dtype=torch.float32, device=dev)
-            _lib.check(lib.ocm_op_attention(0, _p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, float(self.scale), _stream()))
+            _lib.check(lib.ocm_op_attention(pc, _p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, float(self.scale), _stream()))
             attn = torch.empty((B, H, N, N), dtype=torch.float32, device=dev)
-            _lib.check(lib.ocm_op_attention_probs(0, _p(q), _p(k), _p(lse), _p(attn), B, N, H, float(self.scale), _stream()))
+            _lib.check(lib.ocm_op_attention_probs(pc, _p(q), _p(k), _p(lse), _p(attn), B, N, H, float(self.scale), _stream()))
             y = torch.empty((B * N, Cd), dtype=torch.float32, device=dev)
-            _lib.check(lib.ocm_op_linear(0, _p(ctx), _p(self._w[1].get(self.proj.weight)), _p(_bias_or_zeros(self.proj)),
+            _lib.check(lib.ocm_op_linear(pc, _p(ctx), _p(self._w[1].get(self.proj.weight, pc)), _p(_bias_or_zeros(self.proj)),
                                          None, _p(y), B * N, Cd, Cd, _lib.OCM_EPI_BIAS_F32, _stream()))
         return y.reshape(B, N, Cd), attn, qkv
 
