@@ -102,7 +102,8 @@ int ocm_vit_set_param(ocm_vit_t *h, const char *name, const float *dev_src, size
  *   OCM_OPT_FOLD_LN  (OCM_PREC_BF16X3 engines) LayerNorm folded into the GEMM that consumes it: the residual stream is
  *                    handed over un-normalised as split pairs with per-row sums, the consumer multiplies by W * gamma
  *                    and finishes rstd * (acc - mu * c) + d in its epilogue — no LayerNorm launches, no full-row tiles.
- *                    0 = on (ocm_vit_forward; the block-level entry points keep the LayerNorm kernels), 1 = never. */
+ *                    0 = where it is faster (forwards whose (T x D) output holds fewer than 512 tiles of 128 x 128; the
+ *                    block-level entry points keep the LayerNorm kernels), 1 = never, 2 = in every ocm_vit_forward. */
 enum { OCM_OPT_FUSE_LN = 0, OCM_OPT_FOLD_LN = 1, OCM_OPT_COUNT = 2 };
 int ocm_vit_set_option(ocm_vit_t *h, int32_t option, int32_t value);
 /* 0 when every parameter has been set, else OCM_ESTATE with the first missing

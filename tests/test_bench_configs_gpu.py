@@ -76,6 +76,14 @@ def test_config4_slab_sweep_sampled_windows(dev):
     sweep = SlidingWindowAttention(model, window=384, stride=128)  # auto batch plan, as bench.py's slab_sweep
     maps = sweep(slab.to(dev))
     assert maps.shape == (900, 6, 1, 48, 48)
+    # forwards of this size keep their LayerNorm kernels ("auto"); the folded form of the same sweep agrees with them
+    eng = model._engine(dev)
+    try:
+        eng.set_fold_layernorm("always")
+        maps_folded = sweep(slab.to(dev))
+    finally:
+        eng.set_fold_layernorm("auto")
+    assert float((maps_folded - maps).abs().max()) < 1e-6
     origins = sliding_window_origins(4096, 4096, 128)
     assert origins.shape == (900, 2) and tuple(origins[-1]) == (3712, 3712)
     pick = [0, 15 * 30 + 15, 899]  # first corner, centre, last corner

@@ -13,8 +13,9 @@ import sys
 CLASSES = {
     "bf16x3": {
         "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 12,",
-        "fc2_gemm": "gemm_kernel<GemmCfg<64, 384, 2, 4>, sp32, false, 48,",
-        "proj_gemm": "gemm_kernel<GemmCfg<64, 384, 2, 4>, sp32, false, 12,",
+        # round 3: LayerNorm folded into its consumer -> attn.proj / mlp.fc2 on 128 x 192 LDS-DMA tiles (x, split(x), row sums)
+        "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2>, sp32, false, 48,",
+        "proj_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2>, sp32, false, 12,",
         "qkv_gemm": "qkv_dma_kernel<GemmCfg<128, 128, 2, 4>, sp32, 12, 2>",
         "attention": "attn_fwd_x3_dma_kernel<true, 4, 3>",
         "patch_embed": "gemm_kernel<GemmCfg<64, 128, 2, 2>, sp32, false, 24, PatchLoader<",
@@ -22,8 +23,8 @@ CLASSES = {
     # config 4 (ViT-S/8 slab sweep, 20-21 windows of 2305 tokens per launch): summaries of tools/sweep_slab.py runs
     "slab_bf16x3": {
         "attention": "attn_fwd_x3_dma_kernel<true, 8, 2>",
-        "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 48, 2, EpiLinear<1,",  # un-fused at this size
-        "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 12,",
+        "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 48, 2, EpiResidStats<",  # 128 x 128 tiles at this size
+        "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 12, 2, EpiL",
     },
 }
 
@@ -43,7 +44,7 @@ def algorithmic_bytes(prec):
         "proj_gemm": T * D * e + D * D * e + T * D * 4 * 2 + T * D * e,
         "qkv_gemm": T * D * e + D * 3 * D * e + qkv_out,
         "attention": qkv_out + T * D * e,
-        "patch_embed": 64 * 3 * 224 * 224 * 4 + 768 * D * e + T * D * 4,
+        "patch_embed": 64 * 3 * 224 * 224 * 4 + 768 * D * e + T * D * 4 + T * D * e,  # + split(x) for the folded first LayerNorm
     }
 
 

@@ -305,7 +305,7 @@ extern "C" int ocm_vit_set_option(ocm_vit_t *h, int32_t option, int32_t value) {
     if (!h) return fail(OCM_EINVAL, "null handle");
     if (option < 0 || option >= OCM_OPT_COUNT) return fail(OCM_EINVAL, "unknown option %d", option);
     if (option == OCM_OPT_FUSE_LN && (value < 0 || value > 2)) return fail(OCM_EINVAL, "OCM_OPT_FUSE_LN takes 0 (auto), 1 (never) or 2 (always)");
-    if (option == OCM_OPT_FOLD_LN && (value < 0 || value > 1)) return fail(OCM_EINVAL, "OCM_OPT_FOLD_LN takes 0 (auto) or 1 (never)");
+    if (option == OCM_OPT_FOLD_LN && (value < 0 || value > 2)) return fail(OCM_EINVAL, "OCM_OPT_FOLD_LN takes 0 (auto), 1 (never) or 2 (always)");
     if (h->opt[option] != value) h->graph_valid = false;  // a cached launch sequence was recorded under the old setting
     h->opt[option] = value;
     return OCM_OK;
@@ -602,7 +602,12 @@ static int enqueue_forward(ocm_vit *h, const ocm_vit_io *io, int n, hipStream_t 
     int rc;
     const Workspace w = carve(h, B, n, (char *)io->workspace);
     const size_t T = (size_t)B * n;
-    const bool fold = h->folding();
+    // Folding pays where it frees the N = D GEMMs from full-row tiles and removes 2 L LayerNorm launches (ViT-S/16 at
+    // B = 64: -7 % per forward; one tile per call: -3 %). Forwards large enough for 512 tiles of 128 x 128 in the (T x D)
+    // output never used full-row tiles and run their LayerNorm kernels at HBM speed: there the heavier epilogues cost
+    // more than the launches save (4096^2 slab sweep, T = 48 k: 554 -> 561 ms), so "auto" keeps the LayerNorm kernels.
+    const long t128 = (long)((T + 127) / 128) * (h->D / 128);
+    const bool fold = h->folding() && (h->opt[OCM_OPT_FOLD_LN] == 2 || t128 < 512);
     if (fold) {
         if ((rc = run_prepare(h, io, w.x, n, s, w.xn, w.stats))) return rc;
     } else if ((rc = run_prepare(h, io, w.x, n, s))) return rc;

@@ -345,6 +345,7 @@ static hipError_t launch_gemm_dma(const E *a, int64_t lda, const E *w, int64_t l
         case 12: return launch_gemm_dma_ks<Cfg, E, 12, NSTAGE, Epi>(a, lda, w, ldw, M, N, K, epi, s);
         case 24: return launch_gemm_dma_ks<Cfg, E, 24, NSTAGE, Epi>(a, lda, w, ldw, M, N, K, epi, s);
         case 48: return launch_gemm_dma_ks<Cfg, E, 48, NSTAGE, Epi>(a, lda, w, ldw, M, N, K, epi, s);
+        case 96: return launch_gemm_dma_ks<Cfg, E, 96, NSTAGE, Epi>(a, lda, w, ldw, M, N, K, epi, s);  // ViT-B mlp.fc2
         default: break;
     }
     return launch_gemm_dma_ks<Cfg, E, 0, NSTAGE, Epi>(a, lda, w, ldw, M, N, K, epi, s);

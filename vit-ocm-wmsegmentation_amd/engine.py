@@ -85,7 +85,7 @@ class Engine:
         if os.environ.get("OCM_FUSE_LN"):  # "auto" / "never" / "always" (A/B runs; the default is "auto")
             self.set_fuse_layernorm(os.environ["OCM_FUSE_LN"])
         if os.environ.get("OCM_FOLD_LN"):  # "0" switches the folded LayerNorm off (A/B runs)
-            self.set_fold_layernorm(os.environ["OCM_FOLD_LN"] != "0")
+            self.set_fold_layernorm({"0": False, "2": "always"}.get(os.environ["OCM_FOLD_LN"], True))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -202,10 +202,12 @@ class Engine:
         check(self.lib.ocm_vit_set_option(self._h, _lib.OCM_OPT_FUSE_LN, value))
 
     def set_fold_layernorm(self, on):
-        """Per-handle option OCM_OPT_FOLD_LN (split-bf16 engines): True (default) hands the residual stream to the qkv / fc1
-        GEMMs un-normalised and finishes the LayerNorm in their epilogues; False runs LayerNorm kernels (or the fused
-        GEMM + LayerNorm kernels, see set_fuse_layernorm)."""
-        check(self.lib.ocm_vit_set_option(self._h, _lib.OCM_OPT_FOLD_LN, 0 if on else 1))
+        """Per-handle option OCM_OPT_FOLD_LN (split-bf16 engines): True / "auto" (default) hands the residual stream to the
+        qkv / fc1 GEMMs un-normalised and finishes the LayerNorm in their epilogues wherever that is faster (forwards of
+        fewer than ~22 k token rows at D = 384); "always" does so in every forward; False runs LayerNorm kernels (or the
+        fused GEMM + LayerNorm kernels, see set_fuse_layernorm)."""
+        value = 2 if on == "always" else 0 if on in (True, "auto") else 1
+        check(self.lib.ocm_vit_set_option(self._h, _lib.OCM_OPT_FOLD_LN, value))
 
     def graph_stats(self):
         """(replays, captures) of the hipGraph path."""
