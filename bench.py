@@ -338,13 +338,14 @@ def main():
 
     # parity of what was just timed: attention-map L_inf vs the CPU oracle on the FIRST, MIDDLE and LAST tile of the bench
     # batch (a remap or batch-stride slip on later images must show), for the random-init weights of the timed run and for
-    # the sharp (qkv x4) and peaked (qkv x8, attention max ~0.8: what a trained checkpoint looks like) weight sets pushed
-    # through the same engine at the same batch
+    # the sharp (qkv x4) and peaked (attention max 0.8-0.9, what a trained checkpoint looks like: qkv x8 on ViT-S/16, the
+    # geometry's calibrated gain otherwise - synth.stress_variant) weight sets pushed through the same engine at the same batch
     from oracle import vit_oracle as O  # checker
     pick = sorted({0, B // 2, B - 1})
     linf_by_set = {}
     for variant in ("init", "sharp", "peaked"):
-        sd = synth.synth_arch_state_dict(args.arch, p, seed=0, variant=variant)
+        wset = synth.stress_variant(args.arch, p) if variant == "peaked" else variant
+        sd = synth.synth_arch_state_dict(args.arch, p, seed=0, variant=wset)
         cfg = O.make_cfg(sd, p, H)
         ref = O.get_last_selfattention(sd, cfg, x[pick].cpu())
         if variant == "init":
@@ -353,7 +354,7 @@ def main():
             model.load_state_dict(sd)
             got = model._run(x, flags=flags)["attn"][0][pick]
         linf_by_set[variant] = {"linf": float((got.cpu() - ref).abs().max()), "attn_max": round(float(ref.max()), 4),
-                                "tiles_checked": pick}
+                                "tiles_checked": pick, "weights": wset}
     linf = linf_by_set["init"]["linf"]
 
     # HBM bytes per launch of the dominant class: measured offline with rocprofv3 --pmc (separate passes,

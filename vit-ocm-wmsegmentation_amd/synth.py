@@ -71,6 +71,12 @@ def param_shapes(embed_dim, depth, patch_size, in_chans=3, mlp_ratio=4.0, img_si
     return shapes
 
 
+def stress_variant(arch, patch):
+    """The calibrated trained-like weight set of a geometry: the qkv gain that puts the attention maximum at 0.8-0.9 without
+    saturating the softmax (x8 on ViT-S/16, x6.5 on ViT-B/16, x10 on ViT-S/8: tests/golden_cases.py)."""
+    return {("vit_small", 16): "peaked", ("vit_base", 16): "qkv6.5", ("vit_small", 8): "qkv10"}.get((arch, patch), "peaked")
+
+
 def qkv_gain_of(variant):
     """Factor applied to the attn.qkv weights by `variant` (raises on an unknown variant)."""
     if variant in ("init", "full"):
