@@ -30,7 +30,7 @@ typedef struct ocm_swin_config {
     int32_t num_labels;   /* classifier outputs (5 in the reference)                                  */
     float mlp_ratio;      /* 4.0                                                                      */
     float ln_eps;         /* 1e-5                                                                     */
-    int32_t precision;    /* OCM_PREC_BF16 / OCM_PREC_FP32 (ocm_vit.h)                                */
+    int32_t precision;    /* OCM_PREC_BF16 / OCM_PREC_FP32 / OCM_PREC_BF16X3 (ocm_vit.h)              */
     int32_t reserved;
 } ocm_swin_config;
 
@@ -60,7 +60,7 @@ int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_t batch, fl
                      float *last_hidden, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Stand-alone (shifted-)window attention of one SwinLayer (modeling_swin.py:529-563 without the projections):
- * qkv (B*H*W, ld) holds q | k | v (heads*32 channels each) per token in E = bf16 / fp32 (`precision`);
+ * qkv (B*H*W, ld) holds q | k | v (heads*32 channels each) per token in E = bf16 / fp32 / split-bf16 pairs (`precision`; pairs: ld and ldc multiples of 32);
  * ctx (B*H*W, ldc) receives softmax(q k^T / sqrt(32) + bias + shift mask) v at the token's own row.
  * rel_table: (2*ws-1)^2 x heads fp32 device table; scratch: heads*(4096 + ws^4) floats of device memory. */
 int ocm_op_swin_window_attention(int32_t precision, const void *qkv, int32_t ld, void *ctx, int32_t ldc,

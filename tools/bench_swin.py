@@ -40,13 +40,14 @@ def main():
     print(f"swin-tiny 224^2 batch {a.batch} {a.precision}: {dt * 1e3:.2f} ms/step = {a.batch / dt:.0f} images/s "
           f"(~{flops / dt / 1e12:.0f} TFLOP/s); logits[0] = {out.logits[0].cpu().numpy().round(3)}")
     import json
-    peak = 2500.0 if a.precision == "bf16" else 157.3
+    peak = 157.3 if a.precision == "fp32" else 2500.0  # exact-fp32 MFMA / dense bf16 MFMA (split-bf16: 3 MFMAs per product)
     print(json.dumps({"metric": "Swin-T images/s (224x224, BASELINE config 5)", "value": round(a.batch / dt, 1), "unit": "images/s",
                       "ms_per_step": round(dt * 1e3, 3), "dtype": a.precision, "config": {"workload": f"swin-tiny 224^2, batch {a.batch}"},
                       "roofline": {"bound": "mfma", "kernel": "whole forward (GEMMs 60 %, window attention 13 %, LayerNorm 11 %, "
                                    "embedding 6 % of the device time: profiles/r02_kernel_stats_swin.csv)",
                                    "achieved": round(flops / dt / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
-                                   "frac": round(flops / dt / 1e12 / peak, 4), "traffic": None}}))
+                                   "frac": round(flops / dt / 1e12 / peak, 4), "traffic": None,
+                                   "mfma_per_product": 3 if a.precision == "bf16x3" else 1}}))
 
 
 if __name__ == "__main__":

@@ -821,6 +821,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_x3_kernel(const char *__r
 }
 
 
+#ifdef OCM_GEMM_STAMPS
+// development only (make stamps, tools/attn_stamps.py): per-wave timeline of attn_fwd_x3_dma_kernel,
+// [workgroup (blockIdx.y * gridDim.x + blockIdx.x) < 1024][wave < 8][point < 16]
+__device__ unsigned long long g_astamps[1024 * 8 * 16];
+extern "C" int ocm_debug_stamps_attn(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_astamps), (size_t)n * 8);
+}
+#define ASTAMP(k)                                                                                                    \
+    do {                                                                                                             \
+        const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                    \
+        if ((threadIdx.x & 63) == 0 && wg_ < 1024 && (k) < 16)                                                       \
+            g_astamps[(wg_ * 8 + (threadIdx.x >> 6 & 7)) * 16 + (k)] = __builtin_readcyclecounter();                 \
+    } while (0)
+// the constant 100 MHz counter (the same on every XCD), for the entry spread and the span of the grid
+#define ASTAMP_RT(k)                                                                                                 \
+    do {                                                                                                             \
+        const unsigned wg_ = blockIdx.y * gridDim.x + blockIdx.x;                                                    \
+        if ((threadIdx.x & 63) == 0 && wg_ < 1024)                                                                   \
+            g_astamps[(wg_ * 8 + (threadIdx.x >> 6 & 7)) * 16 + (k)] = wall_clock64();                               \
+    } while (0)
+#else
+#define ASTAMP(k) ((void)0)
+#define ASTAMP_RT(k) ((void)0)
+#endif
+
 // LDS-DMA form of attn_fwd_x3_kernel (the dispatched one). Same arithmetic per key, but
 //   * K / V^T tiles of 32 keys go global -> LDS by `buffer_load ... lds` (1 KiB = 8 LDS rows per wave instruction, the
 //     chunk swizzle applied to the per-lane SOURCE offset, the tile index in the scalar offset): no staging registers,
@@ -844,6 +869,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
+    ASTAMP(0);  // entered
+    ASTAMP_RT(12);
     int qblk, bh;
     xcd_remap2(qblk, bh);
     const int q0 = (qblk * NW + wave) * 32;
@@ -904,6 +931,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
     // see that the Q registers are complete, or it re-waits for them inside the loop with a count that also covers the
     // tile in flight). 0x0F70 = vmcnt(0), expcnt / lgkmcnt untouched.
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    ASTAMP(1);  // Q and the first two tiles landed
 
     f32x16 O[2];
 #pragma unroll
@@ -924,6 +952,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        ASTAMP(2 + kt);  // barrier of tile kt passed
 #if !defined(OCM_ABL) || OCM_ABL != 5  // ablation 5: no staging after the prologue
         if (kt + 2 < ntiles) OCM_ATTN_DMA(kt + 2, si);  // into the stage of tile kt-1: everybody is past it
 #endif
@@ -1012,6 +1041,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
         si = si == NSTAGE - 1 ? 0 : si + 1;
     }
 #undef OCM_ATTN_DMA
+    ASTAMP(14);  // key loop done
 
     if (!active) return;
     const float lt = l + __shfl_xor(l, 32, 64);
@@ -1043,6 +1073,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
                 }
         }
     }
+    ASTAMP(15);  // context stores issued
+    ASTAMP_RT(13);
 }
 
 

@@ -96,14 +96,22 @@ hipError_t launch_swin_embed(const float *img, const float *w, const float *bias
 // its 4*C inputs are the four 2x2 neighbours in the order (row0,col0), (row1,col0), (row0,col1), (row1,col1).
 // ------------------------------------------------------------------------------------------
 template <class E>
-__device__ __forceinline__ void store4(E *dst, const f32x4 &v);
+__device__ __forceinline__ void store4(E *row, int c, const f32x4 &v);  // columns c .. c+3 of an operand row
 template <>
-__device__ __forceinline__ void store4<float>(float *dst, const f32x4 &v) { *(f32x4 *)dst = v; }
+__device__ __forceinline__ void store4<float>(float *row, int c, const f32x4 &v) { *(f32x4 *)(row + c) = v; }
 template <>
-__device__ __forceinline__ void store4<bf16>(bf16 *dst, const f32x4 &v) {
+__device__ __forceinline__ void store4<bf16>(bf16 *row, int c, const f32x4 &v) {
     bf16x4 o;
     o[0] = (bf16)v[0]; o[1] = (bf16)v[1]; o[2] = (bf16)v[2]; o[3] = (bf16)v[3];
-    *(bf16x4 *)dst = o;
+    *(bf16x4 *)(row + c) = o;
+}
+template <>
+__device__ __forceinline__ void store4<sp32>(sp32 *row, int c, const f32x4 &v) {  // [32 x hi | 32 x lo] groups (common.h)
+    bf16x4 hi, lo;
+    split4(v, hi, lo);
+    char *p = (char *)row + sp_off(c);
+    *(bf16x4 *)p = hi;
+    *(bf16x4 *)(p + 64) = lo;
 }
 
 // LPR lanes per row (32: two rows per wavefront for dim <= 128; 64 otherwise), V float4 chunks per lane.
@@ -162,12 +170,12 @@ __global__ __launch_bounds__(256) void swin_ln_kernel(const float *__restrict__ 
         const int c = (sub + LPR * i) * 4;
         if (c < dim) {
             const f32x4 gg = *(const f32x4 *)(g + c), bb = *(const f32x4 *)(be + c);
-            store4<E>(dst + c, (v[i] - mean) * rstd * gg + bb);
+            store4<E>(dst, c, (v[i] - mean) * rstd * gg + bb);
         } else if (c < ldy) {
-            store4<E>(dst + c, f32x4{0.f, 0.f, 0.f, 0.f});
+            store4<E>(dst, c, f32x4{0.f, 0.f, 0.f, 0.f});
         }
     }
-    for (int c = (sub + LPR * V) * 4; c < ldy; c += LPR * 4) store4<E>(dst + c, f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int c = (sub + LPR * V) * 4; c < ldy; c += LPR * 4) store4<E>(dst, c, f32x4{0.f, 0.f, 0.f, 0.f});
 }
 
 template <class E, bool MERGE>
@@ -189,6 +197,11 @@ static hipError_t launch_swin_ln_e(const float *x, const float *g, const float *
 hipError_t launch_swin_ln(int prec, const float *x, const float *g, const float *be, void *y, size_t rows, int dim,
                           int ldy, float eps, bool merge, int Hin, int Win, hipStream_t s) {
     if (rows == 0) return hipSuccess;
+    if (prec == 2) {
+        if (ldy % 32) return hipErrorInvalidValue;
+        return merge ? launch_swin_ln_e<sp32, true>(x, g, be, (sp32 *)y, rows, dim, ldy, eps, Hin, Win, s)
+                     : launch_swin_ln_e<sp32, false>(x, g, be, (sp32 *)y, rows, dim, ldy, eps, Hin, Win, s);
+    }
     if (prec) {
         return merge ? launch_swin_ln_e<float, true>(x, g, be, (float *)y, rows, dim, ldy, eps, Hin, Win, s)
                      : launch_swin_ln_e<float, false>(x, g, be, (float *)y, rows, dim, ldy, eps, Hin, Win, s);
@@ -415,6 +428,159 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
     }
 }
 
+// split-bf16 (OCM_PREC_BF16X3): swin_wattn_kernel on [hi | lo] pairs. One head of one token is exactly one 128-byte
+// group of the operand row (head_dim 32: 32 x hi | 32 x lo), so q / k / v fragments are 16-byte pieces of it; scores and
+// context are three MFMAs per product (mfma32x3), the probabilities are split in registers, the context leaves as pairs.
+// LDS per wavefront: K 64 keys x 128 B (hi | lo), V^T 32 dims x (64 keys hi + 64 keys lo) = two [32][128 B] images.
+constexpr int WATTN_X3_WAVES = 3;  // 16.1 KiB of LDS per wavefront: three workgroups of three per CU
+template <int WS>
+__global__ __launch_bounds__(WATTN_X3_WAVES * 64) void swin_wattn_x3_kernel(const char *__restrict__ qkv, int ld, char *__restrict__ ctx,
+                                                            int ldc, const float *__restrict__ bias_perm, WinGeom g,
+                                                            int total, float scale2) {
+    constexpr int PER_WAVE = 64 * 128 + 2 * 32 * 128 + 64;
+    __shared__ __attribute__((aligned(16))) char smem[WATTN_X3_WAVES * PER_WAVE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int id = blockIdx.x * WATTN_X3_WAVES + wave;
+    if (id >= total) return;  // no workgroup barrier below: every wave owns its LDS slice
+    char *Ks = smem + wave * PER_WAVE;  // K: 64 keys x 128 B, chunks 0..3 = hi, 4..7 = lo (lds_off swizzle)
+    char *Vh = Ks + 64 * 128;           // V^T hi: 32 dims x 64 keys; V^T lo follows
+    char *Vl = Vh + 32 * 128;
+    unsigned char *Rg = (unsigned char *)(Vl + 32 * 128);
+    const int head = id % g.heads, wlin = (id / g.heads) % g.nW, b = id / (g.heads * g.nW);
+    const int wy = wlin / g.nWx, wx = wlin - wy * g.nWx;
+    const int ws = WS ? WS : g.ws;
+    const int A = ws * ws, C = g.heads * 32;
+    const size_t ldb = (size_t)ld * 4, ldcb = (size_t)ldc * 4;  // row strides in bytes (4 bytes per element)
+    const char *base = qkv + head * 128;
+
+    // one burst of global loads: the K / V groups of the window's tokens (8 chunks of 16 B per group: lane -> (key, chunk))
+    // and the Q fragments of both query tiles
+    bf16x8 kreg[8], vreg[8], qh[2][2], ql[2][2];
+    size_t qtok[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i, key = idx >> 3, ch = idx & 7;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kreg[i][e] = vreg[i][e] = (bf16)0.f;
+        if (key < A) {
+            const char *row = base + win_token(g, ws, b, wy, wx, key) * ldb + ch * 16;
+            kreg[i] = *(const bf16x8 *)(row + (size_t)C * 4);
+            vreg[i] = *(const bf16x8 *)(row + (size_t)2 * C * 4);
+        }
+    }
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        qtok[qt] = win_token(g, ws, b, wy, wx, min(qt * 32 + r, A - 1));
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const char *p = base + qtok[qt] * ldb + (16 * s + 8 * h) * 2;
+            qh[qt][s] = *(const bf16x8 *)p;
+            ql[qt][s] = *(const bf16x8 *)(p + 64);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = lane + 64 * i, key = idx >> 3, ch = idx & 7;
+        *(bf16x8 *)(Ks + lds_off(key, ch)) = kreg[i];
+        char *vt = ch < 4 ? Vh : Vl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = (ch & 3) * 8 + e;
+            *(bf16 *)(vt + lds_off(d, key >> 3) + (key & 7) * 2) = vreg[i][e];
+        }
+    }
+    const bool masked = g.shift > 0 && (wy == g.H / ws - 1 || wx == g.nWx - 1);  // wave-uniform
+    if (masked) Rg[lane] = (unsigned char)(lane < A ? win_region(g, ws, wy, wx, lane) : 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+
+    const int pr = pi_row(r);
+    const float *bp = bias_perm + (size_t)head * 2 * 64 * 32 + lane * 4;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        if (qt * 32 >= A) break;
+        const int qi = qt * 32 + r;
+        f32x16 S[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S[sub][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 kh = *(const bf16x8 *)(Ks + lds_off(sub * 32 + pr, 2 * s + h));
+                const bf16x8 kl = *(const bf16x8 *)(Ks + lds_off(sub * 32 + pr, 4 + 2 * s + h));
+                S[sub] = mfma32x3(kh, kl, qh[qt][s], ql[qt][s], S[sub]);
+            }
+        }
+        const float *bq = bp + qt * 64 * 32;
+        float mx = -INFINITY;
+        const int myreg = masked ? Rg[min(qi, A - 1)] : 0;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const f32x4 bv = *(const f32x4 *)(bq + (sub * 4 + e4) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(S[sub][e4 * 4 + e], scale2, bv[e]);
+                    if (masked) {
+                        const int j = sub * 32 + key_of_reg(e4 * 4 + e, h);
+                        if (j < A && Rg[j] != myreg) v += -100.0f * 1.4426950408889634f;
+                    }
+                    S[sub][e4 * 4 + e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = fast_exp2(S[sub][e] - mx);
+                S[sub][e] = p;
+                l += p;
+            }
+        l += __shfl_xor(l, 32, 64);
+        f32x16 O;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[e] = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = S[sub][8 * s2 + e];
+                    const bf16 t = (bf16)pv;
+                    ph[e] = t;
+                    pl[e] = (bf16)(pv - (float)t);
+                }
+                const bf16x8 vh = *(const bf16x8 *)(Vh + lds_off(r, 4 * sub + 2 * s2 + h));
+                const bf16x8 vl = *(const bf16x8 *)(Vl + lds_off(r, 4 * sub + 2 * s2 + h));
+                O = mfma32x3(vh, vl, ph, pl, O);
+            }
+        // Lane (r, h) holds dims {8g + 4h + e} in fp32: the pair halves go out as four 8-byte pieces per half
+        if (qi < A) {
+            const float inv = 1.0f / l;
+            char *dst = ctx + qtok[qt] * ldcb + head * 128;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = O[4 * gq + e] * inv;
+                bf16x4 oh, ol;
+                split4(o, oh, ol);
+                char *p = dst + (8 * gq + 4 * h) * 2;
+                *(bf16x4 *)p = oh;
+                *(bf16x4 *)(p + 64) = ol;
+            }
+        }
+    }
+}
+
 // fp32 (OCM_PREC_FP32): one wavefront per (b, window, head); lane = query, K / V rows broadcast from LDS.
 __global__ __launch_bounds__(256) void swin_wattn_f32_kernel(const float *__restrict__ qkv, int ld,
                                                              float *__restrict__ ctx, int ldc,
@@ -491,7 +657,16 @@ hipError_t launch_swin_window_attention(int prec, const void *qkv, int ld, void 
     if (total <= 0 || total > 0x7fffffffL) return hipErrorInvalidValue;
     const unsigned blocks = (unsigned)((total + 3) / 4);
     const float scale = 0.17677669529663687f;  // 32^-0.5 (SwinAttention.scaling :408)
-    if (prec)
+    if (prec == 2) {
+        if (ld % 32 || ldc % 32) return hipErrorInvalidValue;
+        const dim3 gx3((unsigned)((total + WATTN_X3_WAVES - 1) / WATTN_X3_WAVES)), bx3(WATTN_X3_WAVES * 64);
+        if (ws == 7)
+            swin_wattn_x3_kernel<7><<<gx3, bx3, 0, s>>>((const char *)qkv, ld, (char *)ctx, ldc, bias_perm, g,
+                                                                        (int)total, scale * 1.4426950408889634f);
+        else
+            swin_wattn_x3_kernel<0><<<gx3, bx3, 0, s>>>((const char *)qkv, ld, (char *)ctx, ldc, bias_perm, g,
+                                                                        (int)total, scale * 1.4426950408889634f);
+    } else if (prec)
         swin_wattn_f32_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const float *)qkv, ld, (float *)ctx, ldc, bias_dense, g,
                                                                   (int)total, scale);
     else if (ws == 7)
@@ -577,6 +752,10 @@ hipError_t launch_cast_pad(int prec, const float *src, void *dst, size_t rows, i
     const size_t total = rows * Kp;
     unsigned blocks = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     if (blocks == 0) return hipSuccess;
+    if (prec == 2) {  // pair layout: rows are whole groups of 32, no padding to add
+        if (K != Kp || K % 32) return hipErrorInvalidValue;
+        return launch_cast_split(src, dst, total, s);
+    }
     if (prec)
         cast_pad_kernel<float><<<dim3(blocks), dim3(256), 0, s>>>(src, (float *)dst, rows, K, Kp);
     else

@@ -91,7 +91,8 @@ extern "C" int ocm_swin_create(const ocm_swin_config *cfg, ocm_swin_t **out) {
     if (cfg->embed_dim <= 0 || cfg->embed_dim % 32 || cfg->embed_dim > 128)
         return fail(OCM_EINVAL, "embed_dim %d must be a multiple of 32, <= 128", cfg->embed_dim);
     if (cfg->num_labels <= 0) return fail(OCM_EINVAL, "num_labels must be positive");
-    if (cfg->precision != OCM_PREC_BF16 && cfg->precision != OCM_PREC_FP32) return fail(OCM_EINVAL, "bad precision");
+    if (cfg->precision != OCM_PREC_BF16 && cfg->precision != OCM_PREC_FP32 && cfg->precision != OCM_PREC_BF16X3)
+        return fail(OCM_EINVAL, "bad precision");
     int grid = cfg->image_size / 4;
     if (cfg->image_size <= 0 || cfg->image_size % 4) return fail(OCM_EINVAL, "image_size must be a multiple of 4");
     for (int s = 0; s < cfg->num_stages; ++s) {
@@ -112,9 +113,9 @@ extern "C" int ocm_swin_create(const ocm_swin_config *cfg, ocm_swin_t **out) {
 
     ocm_swin *h = new ocm_swin();
     h->cfg = *cfg;
-    h->prec = cfg->precision == OCM_PREC_FP32 ? 1 : 0;
-    h->esz = h->prec ? 4 : 2;
-    h->kstep = h->prec ? 32 : 64;
+    h->prec = cfg->precision == OCM_PREC_FP32 ? 1 : cfg->precision == OCM_PREC_BF16X3 ? 2 : 0;
+    h->esz = h->prec ? 4 : 2;       // split-bf16 pairs are 4 bytes per element too
+    h->kstep = h->prec ? 32 : 64;   // and their K step is one 128-byte group of 32
     const int ws = cfg->window_size, A = ws * ws;
     const std::string e = "swin.embeddings.";
     const int C0 = cfg->embed_dim, Kpe = cfg->num_channels * 16;
@@ -227,6 +228,17 @@ extern "C" int ocm_swin_params_ready(const ocm_swin_t *h) {
 }
 
 namespace {
+// nn.Linear on operand rows of stride lda / output rows of stride ldo. Split-bf16 rows are never padded (every channel
+// count of the model is a multiple of the 32-element group), so that mode takes the dense launcher.
+hipError_t swin_linear(int prec, const void *a, int64_t lda, const void *w, const float *bias, const float *resid,
+                       void *out, int64_t ldo, int M, int N, int K, int epilogue, hipStream_t s) {
+    if (prec == 2) {
+        if (lda != K || ldo != N) return hipErrorInvalidValue;
+        return launch_linear(prec, a, w, bias, resid, out, M, N, K, epilogue, s);
+    }
+    return launch_linear_ld(prec, a, lda, w, bias, resid, out, ldo, M, N, K, epilogue, s);
+}
+
 struct SwinWs {
     float *x, *x2;  // residual stream ping-pong (patch merging writes the other one)
     void *xn, *qkv, *ctx, *hid;
@@ -290,17 +302,17 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
             const int shift = (b % 2 == 1 && H > ws) ? ws / 2 : 0;  // set_shift_and_window_size :576-582
             HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), w.xn, T, C, Kc, eps,
                                    false, 0, 0, s));
-            HIP_TRY(launch_linear_ld(pc, w.xn, Kc, h->ptr<char>(lp.wqkv), h->ptr<float>(lp.bqkv), nullptr, w.qkv, 3 * C,
+            HIP_TRY(swin_linear(pc, w.xn, Kc, h->ptr<char>(lp.wqkv), h->ptr<float>(lp.bqkv), nullptr, w.qkv, 3 * C,
                                      (int)T, 3 * C, Kc, OCM_EPI_BIAS_BF16, s));
             HIP_TRY(launch_swin_window_attention(pc, w.qkv, 3 * C, w.ctx, Kc, h->ptr<float>(lp.bias_perm),
                                                  h->ptr<float>(lp.bias_dense), batch, H, H, ws, shift, heads, s));
-            HIP_TRY(launch_linear_ld(pc, w.ctx, Kc, h->ptr<char>(lp.wo), h->ptr<float>(lp.bo), x, x, C, (int)T, C, Kc,
+            HIP_TRY(swin_linear(pc, w.ctx, Kc, h->ptr<char>(lp.wo), h->ptr<float>(lp.bo), x, x, C, (int)T, C, Kc,
                                      OCM_EPI_BIAS_RESID_F32, s));
             HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln2_g), h->ptr<float>(lp.ln2_b), w.xn, T, C, Kc, eps,
                                    false, 0, 0, s));
-            HIP_TRY(launch_linear_ld(pc, w.xn, Kc, h->ptr<char>(lp.w1), h->ptr<float>(lp.b1), nullptr, w.hid, Km, (int)T, M,
+            HIP_TRY(swin_linear(pc, w.xn, Kc, h->ptr<char>(lp.w1), h->ptr<float>(lp.b1), nullptr, w.hid, Km, (int)T, M,
                                      Kc, OCM_EPI_BIAS_GELU_BF16, s));
-            HIP_TRY(launch_linear_ld(pc, w.hid, Km, h->ptr<char>(lp.w2), h->ptr<float>(lp.b2), x, x, C, (int)T, C, Km,
+            HIP_TRY(swin_linear(pc, w.hid, Km, h->ptr<char>(lp.w2), h->ptr<float>(lp.b2), x, x, C, (int)T, C, Km,
                                      OCM_EPI_BIAS_RESID_F32, s));
         }
         if (st + 1 < c.num_stages) {  // SwinPatchMerging :309-326
@@ -309,7 +321,7 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
             const int K4 = h->Kp(4 * C);
             HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(sp.red_g), h->ptr<float>(sp.red_b), w.xn, T4, 4 * C, K4, 1e-5f, true,
                                    H, H, s));
-            HIP_TRY(launch_linear_ld(pc, w.xn, K4, h->ptr<char>(sp.red_w), nullptr, nullptr, xo, 2 * C, (int)T4, 2 * C, K4,
+            HIP_TRY(swin_linear(pc, w.xn, K4, h->ptr<char>(sp.red_w), nullptr, nullptr, xo, 2 * C, (int)T4, 2 * C, K4,
                                      OCM_EPI_BIAS_F32, s));
             float *t = x;
             x = xo;
@@ -328,14 +340,17 @@ extern "C" int ocm_op_swin_window_attention(int32_t precision, const void *qkv, 
                                             const float *rel_table, float *scratch, int32_t batch, int32_t height,
                                             int32_t width, int32_t window, int32_t shift, int32_t heads, void *stream) {
     if (!qkv || !ctx || !rel_table || !scratch) return fail(OCM_EINVAL, "null argument");
-    if (precision != OCM_PREC_BF16 && precision != OCM_PREC_FP32) return fail(OCM_EINVAL, "bad precision");
+    if (precision != OCM_PREC_BF16 && precision != OCM_PREC_FP32 && precision != OCM_PREC_BF16X3)
+        return fail(OCM_EINVAL, "bad precision");
+    if (precision == OCM_PREC_BF16X3 && (ld % 32 || ldc % 32))
+        return fail(OCM_EINVAL, "split-bf16 rows are whole groups of 32 elements: ld %d, ldc %d", ld, ldc);
     if (window < 2 || window > 7 || height % window || width % window || batch <= 0 || heads <= 0 || shift < 0 ||
         shift >= window)
         return fail(OCM_EINVAL, "bad window geometry");
     hipStream_t s = (hipStream_t)stream;
     float *perm = scratch, *dense = scratch + (size_t)heads * 4096;
     HIP_TRY(launch_swin_bias_perm(rel_table, perm, dense, heads, window, s));
-    HIP_TRY(launch_swin_window_attention(precision == OCM_PREC_FP32 ? 1 : 0, qkv, ld, ctx, ldc, perm, dense, batch, height,
+    HIP_TRY(launch_swin_window_attention(precision == OCM_PREC_FP32 ? 1 : precision == OCM_PREC_BF16X3 ? 2 : 0, qkv, ld, ctx, ldc, perm, dense, batch, height,
                                          width, window, shift, heads, s));
     return OCM_OK;
 }

@@ -77,8 +77,8 @@ class SwinForImageClassification(nn.Module):
                 state_dict[prefix + flat] = state_dict.pop(prefix + key)
 
     def set_precision(self, precision):
-        if precision not in ("bf16", "fp32"):  # the split-bf16 mode is built for the ViT path only
-            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        if precision not in _lib.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_lib.PRECISIONS)}, got {precision!r}")
         if precision != self._precision:
             self.__dict__["_precision"] = precision
             self._drop_engine()
