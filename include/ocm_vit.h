@@ -216,7 +216,7 @@ enum {
  * epilogues then emit E). */
 
 /* nn.Linear: out = epilogue(A[M][K] · W[N][K]^T + bias[N]); A, W of type E row-major,
- * K % 64 == 0, N % 32 == 0. resid may alias out. */
+ * K % 64 == 0 (bf16) or K % 32 == 0 (fp32, split pairs), N % 32 == 0. resid may alias out. */
 int ocm_op_linear(int32_t precision, const void *a, const void *w, const float *bias, const float *resid,
                   void *out, int32_t M, int32_t N, int32_t K, int32_t epilogue, void *stream);
 

@@ -781,7 +781,9 @@ extern "C" int ocm_op_linear(int32_t precision, const void *a, const void *w, co
     int pc = 0, rc = prec_of(precision, &pc);
     if (rc) return rc;
     if (!a || !w || !out) return fail(OCM_EINVAL, "null argument");
-    if (M <= 0 || N <= 0 || N % 32 || K <= 0 || K % 64) return fail(OCM_EINVAL, "bad shape M=%d N=%d K=%d (N%%32, K%%64)", M, N, K);
+    const int kq = pc ? 32 : 64;  // elements per 128-byte operand row: 64 bf16, 32 fp32 or 32 split pairs
+    if (M <= 0 || N <= 0 || N % 32 || K <= 0 || K % kq)
+        return fail(OCM_EINVAL, "bad shape M=%d N=%d K=%d (N%%32, K%%%d)", M, N, K, kq);
     if (pc == 2 && (epilogue == OCM_EPI_BIAS_GELU_BF16 || epilogue == OCM_EPI_BIAS_BF16) && N % 32)
         return fail(OCM_EINVAL, "split-pair outputs need N %% 32 == 0");
     if (epilogue < 0 || epilogue > 3) return fail(OCM_EINVAL, "bad epilogue %d", epilogue);

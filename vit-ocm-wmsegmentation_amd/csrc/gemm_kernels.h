@@ -9,6 +9,7 @@
 // (kernels_gemm_inst.hip, compiled six times by the Makefile so that the library builds in parallel); the precision
 // switches that call them live in kernels_gemm.hip.
 #pragma once
+#include <type_traits>
 #include "gemm_core.h"
 #include "launch.h"
 #include "dev_knobs.h"
@@ -219,6 +220,7 @@ struct EpiLinear {
 template <class OE>
 struct EpiResidStats {
     static constexpr bool ROWTAB = false;
+    static constexpr int BN_MULT = 64;  // tile widths this epilogue can serve
     const float *bias;
     const float *resid;
     float *x;
@@ -356,6 +358,16 @@ typedef GemmCfg<256, 128, 4, 2> Cfg256x128;
 // 40 KiB of operands for 1152 cycles of MFMA per SIMD, against 56 KiB for the 64 x 384 full-row tile
 typedef GemmCfg<128, 192, 4, 2> Cfg128x192;
 typedef GemmCfg<128, 256, 2, 4> Cfg128x256;
+// Swin's channel counts that are not multiples of 128 (96 and 288 = 3 x 96): the same 32 x 96 wave tile, four waves
+typedef GemmCfg<128, 96, 4, 1> Cfg128x96;
+template <class Epi, class = void>
+struct epi_bn_mult {
+    static constexpr int v = 1;
+};
+template <class Epi>
+struct epi_bn_mult<Epi, std::void_t<decltype(Epi::BN_MULT)>> {
+    static constexpr int v = Epi::BN_MULT;
+};
 
 template <int MODE, class E, class Epi>
 static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int M, int N, int K, hipStream_t s) {
@@ -396,6 +408,14 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             return launch_gemm_dma<Cfg128x192, E, 3>(a, K, w, K, M, N, K, epi, s);
         if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512)
             return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
+        // Swin-T's narrow stages (N = 96, 192, 288, 576 at 2e5 .. 8e5 rows): tiles that divide N exactly on the LDS-DMA
+        // loop instead of 64 x 64 register-staged tiles with a ragged last column (these GEMMs are bound by the 4-byte
+        // activations they stream, not by the matrix pipe)
+        if (N % 128 != 0 && M >= 4096) {
+            if (N % 192 == 0) return launch_gemm_dma<Cfg128x192, E, 3>(a, K, w, K, M, N, K, epi, s);
+            if constexpr (Cfg128x96::BN % epi_bn_mult<Epi>::v == 0)
+                if (N % 96 == 0) return launch_gemm_dma<Cfg128x96, E, 2>(a, K, w, K, M, N, K, epi, s);
+        }
     }
 #ifdef OCM_DEV
     if constexpr (Elem<E>::MODE == 0) {  // development A/B: the LDS-DMA loop on single-bf16 operands (knob 0 = 4 / 7)
