@@ -59,6 +59,20 @@ size_t ocm_swin_workspace_bytes(const ocm_swin_t *h, int32_t batch);
 int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_t batch, float *logits, float *pooled,
                      float *last_hidden, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Per-handle dispatch options. OCM_SWIN_OPT_FUSE_MLP (default 1): in split-bf16 precision the MLP half of the layers of
+ * the narrow stages (96 or 128 channels) runs as ONE kernel (ocm_op_swin_mlp); 0 runs LayerNorm, fc1 + GELU and
+ * fc2 + residual as three launches. Results agree to fp32 rounding. */
+enum { OCM_SWIN_OPT_FUSE_MLP = 0 };
+int ocm_swin_set_option(ocm_swin_t *h, int32_t option, int32_t value);
+
+/* MLP half of one SwinLayer (modeling_swin.py:668-672: layernorm_after, SwinIntermediate, SwinOutput, residual) in one
+ * kernel: x (tokens, channels) fp32, in place, x += W2 gelu(W1 LayerNorm(x; gamma, beta, eps) + b1) + b2. Built for
+ * precision OCM_PREC_BF16X3 (w1 (hidden, channels) and w2 (channels, hidden) as split pairs, ocm_op_cast_split),
+ * channels 96 or 128, hidden = 4 x channels; anything else returns OCM_EINVAL. */
+int ocm_op_swin_mlp(int32_t precision, float *x, const float *gamma, const float *beta, const void *w1, const float *b1,
+                    const void *w2, const float *b2, int64_t tokens, int32_t channels, int32_t hidden, float eps,
+                    void *stream);
+
 /* Stand-alone (shifted-)window attention of one SwinLayer (modeling_swin.py:529-563 without the projections):
  * qkv (B*H*W, ld) holds q | k | v (heads*32 channels each) per token in E = bf16 / fp32 / split-bf16 pairs (`precision`; pairs: ld and ldc multiples of 32);
  * ctx (B*H*W, ldc) receives softmax(q k^T / sqrt(32) + bias + shift mask) v at the token's own row.

@@ -144,6 +144,55 @@ def test_swin_matches_transformers_fixture(dev, name, precision, tol):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("T,Cn", [(3136, 96), (1000, 96), (33, 96), (700, 128)])
+def test_swin_fused_mlp_op(lib, dev, T, Cn):
+    """ocm_op_swin_mlp (LayerNorm + fc1 + GELU + fc2 + residual in one kernel, split-bf16) against float64 torch on the
+    same parameters (modeling_swin.py:668-672); token counts with full, partial and single workgroups."""
+    from vit_ocm_wmsegmentation_amd.engine import to_operand
+    g = torch.Generator().manual_seed(T + Cn)
+    x = torch.randn(T, Cn, generator=g) * 2 + 0.3
+    gam, bet = torch.randn(Cn, generator=g) * 0.2 + 1, torch.randn(Cn, generator=g) * 0.1
+    w1, b1 = torch.randn(4 * Cn, Cn, generator=g) * 0.08, torch.randn(4 * Cn, generator=g) * 0.1
+    w2, b2 = torch.randn(Cn, 4 * Cn, generator=g) * 0.05, torch.randn(Cn, generator=g) * 0.1
+    xd = x.double()
+    h = torch.nn.functional.gelu(torch.nn.functional.layer_norm(xd, (Cn,), gam.double(), bet.double(), 1e-5) @ w1.double().t()
+                                 + b1.double())
+    want = xd + h @ w2.double().t() + b2.double()
+    xg = x.to(dev)
+    w1s, w2s = to_operand(w1.to(dev), _lib.OCM_PREC_BF16X3), to_operand(w2.to(dev), _lib.OCM_PREC_BF16X3)
+    dv = [t.to(dev) for t in (gam, bet, b1, b2)]
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ocm_op_swin_mlp(_lib.OCM_PREC_BF16X3, p(xg), p(dv[0]), p(dv[1]), p(w1s), p(dv[2]), p(w2s), p(dv[3]), T, Cn,
+                                   4 * Cn, 1e-5, st))
+    err = (xg.cpu().double() - want).abs().max().item()
+    print(f"GPUTEST swin fused mlp T={T} C={Cn}: max|d| = {err:.2e}")
+    assert err <= 5e-5
+    assert lib.ocm_op_swin_mlp(_lib.OCM_PREC_BF16, p(xg), p(dv[0]), p(dv[1]), p(w1s), p(dv[2]), p(w2s), p(dv[3]), T, Cn, 4 * Cn,
+                               1e-5, st) == _lib.OCM_EINVAL
+    assert lib.ocm_op_swin_mlp(_lib.OCM_PREC_BF16X3, p(xg), p(dv[0]), p(dv[1]), p(w1s), p(dv[2]), p(w2s), p(dv[3]), T, 192, 768,
+                               1e-5, st) == _lib.OCM_EINVAL
+
+
+@pytest.mark.gpu
+def test_swin_fused_mlp_agrees_with_three_launches(lib, dev):
+    """OCM_SWIN_OPT_FUSE_MLP on / off: the same model, logits and hidden states agree to fp32 rounding."""
+    c, cfg, sd, x = _case("tiny224")
+    hf = SW.SwinConfig(image_size=cfg["image_size"], depths=cfg["depths"], num_heads=cfg["num_heads"], num_labels=cfg["num_labels"])
+    model = SW.SwinForImageClassification(hf)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval().set_precision("bf16x3")
+    a = model(pixel_values=x.to(dev), output_hidden_states=True)
+    _lib.check(lib.ocm_swin_set_option(model._engine["h"], _lib.OCM_SWIN_OPT_FUSE_MLP, 0))
+    b = model(pixel_values=x.to(dev), output_hidden_states=True)
+    assert lib.ocm_swin_set_option(model._engine["h"], 7, 0) == _lib.OCM_EINVAL
+    d = (a.logits - b.logits).abs().max().item()
+    dh = (a.last_hidden_state - b.last_hidden_state).abs().max().item()
+    print(f"GPUTEST swin fused vs unfused mlp: logits {d:.2e}, hidden {dh:.2e}")
+    assert d <= 2e-5 and dh <= 2e-4 and d + dh > 0  # the two paths really differ (and only in rounding)
+
+
+@pytest.mark.gpu
 def test_swin_single_channel_batch_one_vs_oracle(dev):
     """Edge geometry: one grayscale plane (num_channels = 1, K = 16 patch values) and a batch of one, against the
     (transformers-pinned) oracle run on the same synthetic weights."""

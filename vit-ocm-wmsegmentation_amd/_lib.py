@@ -16,6 +16,7 @@ OCM_OK, OCM_EINVAL, OCM_ESTATE, OCM_EHIP, OCM_ENOMEM, OCM_ENAME = 0, 1, 2, 3, 4,
 OCM_PREC_BF16 = 0
 OCM_PREC_FP32 = 1
 OCM_PREC_BF16X3 = 2
+OCM_SWIN_OPT_FUSE_MLP = 0
 PRECISIONS = {"bf16": OCM_PREC_BF16, "fp32": OCM_PREC_FP32, "bf16x3": OCM_PREC_BF16X3}
 DEFAULT_PRECISION = "bf16x3"  # the mode that holds the north star's 1e-3 on every golden weight set
 OCM_LN_F32, OCM_LN_BF16, OCM_LN_SPLIT = 0, 1, 2
@@ -144,6 +145,9 @@ SIGNATURES = {
     "ocm_swin_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
     "ocm_swin_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p]),
+    "ocm_swin_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "ocm_op_swin_mlp": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "ocm_op_swin_window_attention": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                                C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                C.c_int32, C.c_void_p]),

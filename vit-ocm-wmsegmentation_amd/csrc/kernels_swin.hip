@@ -679,6 +679,207 @@ hipError_t launch_swin_window_attention(int prec, const void *qkv, int ld, void 
 }
 
 // ------------------------------------------------------------------------------------------
+// MLP half of a SwinLayer in one kernel (split-bf16, narrow stages: C = 96 or 128)
+//     x += fc2(gelu(fc1(LayerNorm(x))))            modeling_swin.py SwinLayer.forward :668-672, SwinIntermediate / SwinOutput
+// At 8e5 token rows and C = 96 the unfused chain (LayerNorm, fc1 + GELU, fc2 + residual) streams 4 GB per layer, most of
+// it the 4C-wide hidden activations (4 bytes per element as split pairs): it runs at the HBM rate, not the matrix rate.
+// Here a wavefront owns 32 tokens and keeps everything that belongs to them on chip:
+//   * LayerNorm of its rows in registers, split into pairs: the B operand x^T of the first product (2 * C / 16 fragments);
+//   * hidden^T (32 hidden units x 32 tokens per step) = W1 rows . x^T with the W1 rows in pi order (common.h), so that
+//     after bias + GELU the accumulator registers ARE the B operand fragments of the second product (the scheme of the
+//     attention kernels, kernels_attn.hip): y^T (C x 32 tokens) += W2[:, step] . hidden^T;
+//   * W1 / W2 pass through a three-stage `buffer_load ... lds` ring shared by the eight wavefronts of the workgroup (24 KiB
+//     per step of 32 hidden units at C = 96), one counted vmcnt wait and one barrier per step;
+//   * epilogue: + b2 + x, fp32, in place. HBM traffic: x once in, once out.
+// ------------------------------------------------------------------------------------------
+template <int CG, int HG>  // C / 32, hidden / 32
+__global__ __launch_bounds__(512, 2) void swin_mlp_x3_kernel(float *__restrict__ x, const float *__restrict__ gam,
+                                                             const float *__restrict__ bet, const char *__restrict__ w1,
+                                                             const float *__restrict__ b1, const char *__restrict__ w2,
+                                                             const float *__restrict__ b2, int T, float eps) {
+    constexpr int C = CG * 32, HID = HG * 32, W1B = CG * 4096, STAGE = W1B + C * 128, NSTAGE = 3;
+    constexpr int PIECES = STAGE / 1024, PPW = PIECES / 8, NS = 2 * CG;  // 1-KiB DMA pieces per step / per wave; k slices of 16
+    static_assert(PIECES % 8 == 0, "eight wavefronts share the pieces of a step evenly");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    float *b1s = (float *)(smem + NSTAGE * STAGE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int tok0 = blockIdx.x * 256 + wave * 32;
+    const bool live = tok0 + r < T;
+    const size_t tok = (size_t)min(tok0 + r, T - 1);
+
+    for (int i = tid; i < HID; i += 512) b1s[i] = b1[i];
+
+    // piece pc = jj * 8 + wave of a step: pieces [0, 4 CG) = W1 (image pc >> 2 = k group, rows (pc & 3) * 8 .. + 7 of the
+    // step's 32 hidden units), the rest = W2 (rows (pc - 4 CG) * 8 .. + 7 of the C outputs, the step's k group)
+    int voff[PPW];
+    {
+        const int lrow = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int jj = 0; jj < PPW; ++jj) {
+            const int pc = jj * 8 + wave;
+            if (pc < 4 * CG) {
+                const int rho = (pc & 3) * 8 + lrow;
+                voff[jj] = rho * (C * 4) + (pc >> 2) * 128 + ((slot ^ ((rho >> 1) & 7)) << 4);
+            } else {
+                const int c = (pc - 4 * CG) * 8 + lrow;
+                voff[jj] = c * (HID * 4) + ((slot ^ ((c >> 1) & 7)) << 4);
+            }
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void *)w1, 0, (unsigned)(HID * C * 4), 0x00020000);
+    const auto rs2 = __builtin_amdgcn_make_buffer_rsrc((void *)w2, 0, (unsigned)(HID * C * 4), 0x00020000);
+#define OCM_MLP_DMA(j, st)                                                                                               \
+    do {                                                                                                                 \
+        _Pragma("unroll") for (int jj = 0; jj < PPW; ++jj) {                                                             \
+            const int pc = jj * 8 + wave;                                                                                \
+            char *dst_ = smem + (st) * STAGE + pc * 1024;                                                                \
+            if (pc < 4 * CG)                                                                                             \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)dst_, 16, voff[jj], (j) * (32 * C * 4), 0, 0);    \
+            else                                                                                                         \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, (lds_ptr)dst_, 16, voff[jj], (j) * 128, 0, 0);             \
+        }                                                                                                                \
+    } while (0)
+#else
+#define OCM_MLP_DMA(j, st) (void)0
+#endif
+    OCM_MLP_DMA(0, 0);
+    if (HG > 1) OCM_MLP_DMA(1, 1);
+
+    // LayerNorm of the wave's rows: lane (r, h) holds channels 16 s + 8 h .. + 7 of token r for every slice s
+    bf16x8 xh[NS], xl[NS];
+    {
+        const float *xr = x + tok * C + 8 * h;
+        f32x4 v[NS][2];
+        float sum = 0.f;
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            v[sI][0] = *(const f32x4 *)(xr + 16 * sI);
+            v[sI][1] = *(const f32x4 *)(xr + 16 * sI + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += v[sI][0][e] + v[sI][1][e];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / C);
+        float var = 0.f;
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d0 = v[sI][0][e] - mean, d1 = v[sI][1][e] - mean;
+                var = fmaf(d0, d0, fmaf(d1, d1, var));
+            }
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = rsqrtf(var * (1.0f / C) + eps);
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            const f32x4 g0 = *(const f32x4 *)(gam + 16 * sI + 8 * h), g1 = *(const f32x4 *)(gam + 16 * sI + 8 * h + 4);
+            const f32x4 e0 = *(const f32x4 *)(bet + 16 * sI + 8 * h), e1 = *(const f32x4 *)(bet + 16 * sI + 8 * h + 4);
+            split8((v[sI][0] - mean) * rstd * g0 + e0, (v[sI][1] - mean) * rstd * g1 + e1, xh[sI], xl[sI]);
+        }
+    }
+    // rows, parameters and the first two steps have landed (the builtin, so that hipcc's own bookkeeping sees it and does
+    // not wait again inside the loop with a count that covers the step in flight)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    f32x16 Y[CG];
+#pragma unroll
+    for (int mf = 0; mf < CG; ++mf)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Y[mf][e] = 0.f;
+    const int pr = pi_row(r);
+    int sc = 0, si = 2;
+    for (int j = 0; j < HG; ++j) {
+        if (j + 1 < HG)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 2 < HG) OCM_MLP_DMA(j + 2, si);
+        const char *W1s = smem + sc * STAGE, *W2s = W1s + W1B;
+        f32x16 S;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] = 0.f;
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            const char *img = W1s + (sI >> 1) * 4096;
+            const bf16x8 ah = *(const bf16x8 *)(img + lds_off(pr, (sI & 1) * 2 + h));
+            const bf16x8 al = *(const bf16x8 *)(img + lds_off(pr, 4 + (sI & 1) * 2 + h));
+            S = mfma32x3(ah, al, xh[sI], xl[sI], S);
+        }
+        // register e of lane half h holds hidden unit 32 j + key_of_reg(e, h): registers 0..7 and 8..15 are runs of eight
+        bf16x8 ph[2], pl[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const float *bp = b1s + 32 * j + 16 * s2 + 8 * h;
+            const f32x4 c0 = *(const f32x4 *)bp, c1 = *(const f32x4 *)(bp + 4);
+            f32x4 u0, u1;
+#pragma unroll
+            for (int e = 0; e < 4; e += 2) {
+                const f32x2 a = gelu_erf2(f32x2{S[8 * s2 + e] + c0[e], S[8 * s2 + e + 1] + c0[e + 1]});
+                const f32x2 b = gelu_erf2(f32x2{S[8 * s2 + 4 + e] + c1[e], S[8 * s2 + 4 + e + 1] + c1[e + 1]});
+                u0[e] = a[0]; u0[e + 1] = a[1];
+                u1[e] = b[0]; u1[e + 1] = b[1];
+            }
+            split8(u0, u1, ph[s2], pl[s2]);
+        }
+#pragma unroll
+        for (int mf = 0; mf < CG; ++mf)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 vh = *(const bf16x8 *)(W2s + lds_off(32 * mf + r, 2 * s2 + h));
+                const bf16x8 vl = *(const bf16x8 *)(W2s + lds_off(32 * mf + r, 4 + 2 * s2 + h));
+                Y[mf] = mfma32x3(vh, vl, ph[s2], pl[s2], Y[mf]);
+            }
+        sc = sc == NSTAGE - 1 ? 0 : sc + 1;
+        si = si == NSTAGE - 1 ? 0 : si + 1;
+    }
+#undef OCM_MLP_DMA
+    if (!live) return;
+    // y^T: lane (r, h) register 4 g + e of fragment mf = channel 32 mf + 8 g + 4 h + e of token r
+    float *xo = x + tok * C;
+#pragma unroll
+    for (int mf = 0; mf < CG; ++mf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = 32 * mf + 8 * g + 4 * h;
+            const f32x4 old = *(const f32x4 *)(xo + c), bb = *(const f32x4 *)(b2 + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = Y[mf][4 * g + e] + bb[e] + old[e];
+            *(f32x4 *)(xo + c) = o;
+        }
+}
+
+bool swin_mlp_fused_supported(int prec, int C, int hidden) { return prec == 2 && hidden == 4 * C && (C == 96 || C == 128); }
+
+hipError_t launch_swin_mlp(int prec, float *x, const float *g, const float *be, const void *w1, const float *b1,
+                           const void *w2, const float *b2, size_t T, int C, int hidden, float eps, hipStream_t s) {
+    if (!swin_mlp_fused_supported(prec, C, hidden) || T == 0 || T > 0x7fffffffu) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((T + 255) / 256)), block(512);
+    const int lds = 3 * (C / 32 * 4096 + C * 128) + hidden * 4;
+    static unsigned long long optin[2] = {0, 0};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const void *kern = C == 96 ? (const void *)swin_mlp_x3_kernel<3, 12> : (const void *)swin_mlp_x3_kernel<4, 16>;
+    unsigned long long &mask = optin[C == 96 ? 0 : 1];
+    if (!(mask >> (dev & 63) & 1)) {
+        if (hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); e != hipSuccess) return e;
+        mask |= 1ull << (dev & 63);
+    }
+    if (C == 96)
+        swin_mlp_x3_kernel<3, 12><<<grid, block, lds, s>>>(x, g, be, (const char *)w1, b1, (const char *)w2, b2, (int)T, eps);
+    else
+        swin_mlp_x3_kernel<4, 16><<<grid, block, lds, s>>>(x, g, be, (const char *)w1, b1, (const char *)w2, b2, (int)T, eps);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // final LayerNorm + AdaptiveAvgPool1d(1) + classifier: one workgroup per image
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void swin_pool_head_kernel(const float *__restrict__ x, const float *__restrict__ g,

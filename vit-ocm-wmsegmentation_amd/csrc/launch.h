@@ -128,6 +128,10 @@ hipError_t launch_swin_bias_perm(const float *table, float *perm, float *dense, 
 hipError_t launch_swin_window_attention(int prec, const void *qkv, int ld, void *ctx, int ldc, const float *bias_perm,
                                         const float *bias_dense, int batch, int H, int W, int ws, int shift, int heads,
                                         hipStream_t s);
+// SwinLayer's MLP half in one kernel (split-bf16, C = 96 / 128, hidden = 4 C): x += fc2(gelu(fc1(LayerNorm(x))))
+bool swin_mlp_fused_supported(int prec, int C, int hidden);
+hipError_t launch_swin_mlp(int prec, float *x, const float *g, const float *be, const void *w1, const float *b1,
+                           const void *w2, const float *b2, size_t T, int C, int hidden, float eps, hipStream_t s);
 hipError_t launch_swin_pool_head(const float *x, const float *g, const float *be, const float *cw, const float *cb,
                                  float *logits, float *pooled, float *hidden, int batch, int L, int C, int labels,
                                  float eps, hipStream_t s);

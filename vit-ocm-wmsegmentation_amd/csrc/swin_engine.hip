@@ -57,6 +57,7 @@ struct ocm_swin {
     size_t emb_w, emb_b, emb_g, emb_be, fin_g, fin_b, cls_w, cls_b;
     char *arena = nullptr;
     size_t arena_bytes = 0;
+    bool fuse_mlp = true;  // ocm_swin_set_option(OCM_SWIN_OPT_FUSE_MLP)
 
     size_t reserve(size_t bytes) {
         const size_t off = arena_bytes;
@@ -308,6 +309,11 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
                                                  h->ptr<float>(lp.bias_dense), batch, H, H, ws, shift, heads, s));
             HIP_TRY(swin_linear(pc, w.ctx, Kc, h->ptr<char>(lp.wo), h->ptr<float>(lp.bo), x, x, C, (int)T, C, Kc,
                                      OCM_EPI_BIAS_RESID_F32, s));
+            if (h->fuse_mlp && swin_mlp_fused_supported(pc, C, M)) {  // narrow stages: the hidden activations stay on chip
+                HIP_TRY(launch_swin_mlp(pc, x, h->ptr<float>(lp.ln2_g), h->ptr<float>(lp.ln2_b), h->ptr<char>(lp.w1),
+                                        h->ptr<float>(lp.b1), h->ptr<char>(lp.w2), h->ptr<float>(lp.b2), T, C, M, eps, s));
+                continue;
+            }
             HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln2_g), h->ptr<float>(lp.ln2_b), w.xn, T, C, Kc, eps,
                                    false, 0, 0, s));
             HIP_TRY(swin_linear(pc, w.xn, Kc, h->ptr<char>(lp.w1), h->ptr<float>(lp.b1), nullptr, w.hid, Km, (int)T, M,
@@ -333,6 +339,28 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
     HIP_TRY(launch_swin_pool_head(x, h->ptr<float>(h->fin_g), h->ptr<float>(h->fin_b), h->ptr<float>(h->cls_w),
                                   h->ptr<float>(h->cls_b), logits, pooled, last_hidden, batch, H * H, Cl, c.num_labels, eps,
                                   s));
+    return OCM_OK;
+}
+
+extern "C" int ocm_swin_set_option(ocm_swin_t *h, int32_t option, int32_t value) {
+    if (!h) return fail(OCM_EINVAL, "null handle");
+    if (option != OCM_SWIN_OPT_FUSE_MLP) return fail(OCM_EINVAL, "unknown Swin option %d", option);
+    if (value != 0 && value != 1) return fail(OCM_EINVAL, "OCM_SWIN_OPT_FUSE_MLP takes 0 or 1, got %d", value);
+    h->fuse_mlp = value != 0;
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_swin_mlp(int32_t precision, float *x, const float *gamma, const float *beta, const void *w1,
+                               const float *b1, const void *w2, const float *b2, int64_t tokens, int32_t channels,
+                               int32_t hidden, float eps, void *stream) {
+    if (!x || !gamma || !beta || !w1 || !b1 || !w2 || !b2) return fail(OCM_EINVAL, "null argument");
+    const int pc = precision == OCM_PREC_FP32 ? 1 : precision == OCM_PREC_BF16X3 ? 2 : precision == OCM_PREC_BF16 ? 0 : -1;
+    if (pc < 0) return fail(OCM_EINVAL, "bad precision");
+    if (tokens <= 0 || tokens > 0x7fffffffLL) return fail(OCM_EINVAL, "bad token count %lld", (long long)tokens);
+    if (!swin_mlp_fused_supported(pc, channels, hidden))
+        return fail(OCM_EINVAL, "the fused MLP is built for split-bf16 operands, channels 96 or 128 and hidden = 4 x channels "
+                                "(got precision %d, %d, %d)", precision, channels, hidden);
+    HIP_TRY(launch_swin_mlp(pc, x, gamma, beta, w1, b1, w2, b2, (size_t)tokens, channels, hidden, eps, (hipStream_t)stream));
     return OCM_OK;
 }
 
