@@ -14,80 +14,120 @@
 #include "launch.h"
 
 // ------------------------------------------------------------------------------------------
-// patch embedding: one wavefront per token, weights of the lane's output channels in registers, the 48 patch
-// values broadcast lane -> scalar with v_readlane
+// patch embedding + LayerNorm (SwinEmbeddings :273-291: Conv2d(k = 4, stride 4), flatten, LayerNorm) on the exact-fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: fp32 products, so every precision mode starts from the same fp32 residual stream).
+// A wavefront owns 32 tokens: y^T (C0 channels x 32 tokens) = W (C0 x K) . patch^T (K x 32), K = 16 * channels. The lane's
+// token is its accumulator COLUMN, so the 4 x 4 patch is twelve (or four) 16-byte loads per lane, coalesced over the 32
+// neighbouring patches of an image row, and the LayerNorm statistics of a token are a sum over the lane's registers plus one
+// lane <-> lane + 32 exchange. W stays in registers across a grid-stride loop over token tiles.
 // ------------------------------------------------------------------------------------------
-template <int U>  // output channels per lane: C0 <= 64 * U
+template <int CH, int CF>  // input channels (1 or 3), C0 / 32
 __global__ __launch_bounds__(256) void swin_embed_kernel(const float *__restrict__ img, const float *__restrict__ w,
                                                          const float *__restrict__ bias, const float *__restrict__ g,
-                                                         const float *__restrict__ be, float *__restrict__ x, int B,
-                                                         int chans, int S, int C0, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int gw = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
-    const int hp = S / 4, K = chans * 16;  // K <= 64
-    float wr[U][48], br[U], gr[U], ber[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int c = min(lane + 64 * u, C0 - 1);
-        br[u] = bias[c];
-        gr[u] = g[c];
-        ber[u] = be[c];
-#pragma unroll
-        for (int k = 0; k < 48; ++k) wr[u][k] = k < K ? w[c * K + k] : 0.f;
+                                                         const float *__restrict__ be, float *__restrict__ x, int B, int S,
+                                                         float eps) {
+    constexpr int K = CH * 16, KK = K / 2, C0 = CF * 32;
+    __shared__ __attribute__((aligned(16))) float par[3 * C0];  // bias | gamma | beta
+    for (int i = threadIdx.x; i < C0; i += 256) {
+        par[i] = bias[i];
+        par[C0 + i] = g[i];
+        par[2 * C0 + i] = be[i];
     }
-    const int ch = lane >> 4, dy = (lane >> 2) & 3, dx = lane & 3;  // lane -> (channel, dy, dx) of the patch
-    const size_t T = (size_t)B * hp * hp;
-    auto pixel = [&](size_t t) {  // this lane's input value of token t (clamped: the stream is unconditional)
-        t = t < T ? t : T - 1;
-        const int b = (int)(t / (hp * hp)), pi = (int)(t - (size_t)b * hp * hp);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int gw = (blockIdx.x * 256 + threadIdx.x) >> 6, nw = (gridDim.x * 256) >> 6;
+    const int hp = S / 4;
+    const size_t T = (size_t)B * hp * hp, tiles = (T + 31) / 32;
+    float wa[CF][KK];  // A operand of k step kk: W[32 mf + r][2 kk + h]
+#pragma unroll
+    for (int mf = 0; mf < CF; ++mf)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) wa[mf][kk] = w[(32 * mf + r) * K + 2 * kk + h];
+    for (size_t tile = gw; tile < tiles; tile += nw) {
+        const size_t t = tile * 32 + r, tc = t < T ? t : T - 1;
+        const int b = (int)(tc / ((size_t)hp * hp)), pi = (int)(tc - (size_t)b * hp * hp);
         const int py = pi / hp, px = pi - py * hp;
-        return lane < K ? img[(((size_t)b * chans + ch) * S + py * 4 + dy) * S + px * 4 + dx] : 0.f;
-    };
-    float vn = pixel(gw), vn2 = pixel(gw + nw);
-    for (size_t t = gw; t < T; t += nw) {
-        const float v = vn;
-        vn = vn2;
-        vn2 = pixel(t + 2 * (size_t)nw);  // two tokens ahead: the HBM round trip overlaps two iterations of FMAs
-        float acc[U];
+        const float *p = img + (((size_t)b * CH) * S + py * 4) * S + px * 4;
+        f32x4 pv[CH][4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc[u] = br[u];
+        for (int ch = 0; ch < CH; ++ch)
 #pragma unroll
-        for (int k = 0; k < 48; ++k) {
-            const float s = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+            for (int dy = 0; dy < 4; ++dy) pv[ch][dy] = *(const f32x4 *)(p + ((size_t)ch * S + dy) * S);
+        f32x16 acc[CF];
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc[u] = fmaf(s, wr[u][k], acc[u]);
-        }
+        for (int mf = 0; mf < CF; ++mf)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[mf][e] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < CH; ++ch)
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                for (int dp = 0; dp < 2; ++dp) {  // k = 16 ch + 4 dy + 2 dp + h
+                    const float bv = h ? pv[ch][dy][2 * dp + 1] : pv[ch][dy][2 * dp];
+#pragma unroll
+                    for (int mf = 0; mf < CF; ++mf) acc[mf] = mfma32f(wa[mf][ch * 8 + dy * 2 + dp], bv, acc[mf]);
+                }
+        // register 4 q + e of fragment mf = channel 32 mf + 8 q + 4 h + e of the lane's token
         float sum = 0.f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) sum += (lane + 64 * u < C0) ? acc[u] : 0.f;
+        for (int mf = 0; mf < CF; ++mf)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        const float mean = sum / (float)C0;
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bb = *(const f32x4 *)(par + 32 * mf + 8 * q + 4 * h);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[mf][4 * q + e] += bb[e];
+                    sum += acc[mf][4 * q + e];
+                }
+            }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / C0);
         float var = 0.f;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const float d = acc[u] - mean;
-            var += (lane + 64 * u < C0) ? d * d : 0.f;
+        for (int mf = 0; mf < CF; ++mf)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float d = acc[mf][e] - mean;
+                var = fmaf(d, d, var);
+            }
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = rsqrtf(var * (1.0f / C0) + eps);
+        if (t < T) {
+            float *xo = x + t * C0;
+#pragma unroll
+            for (int mf = 0; mf < CF; ++mf)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = 32 * mf + 8 * q + 4 * h;
+                    const f32x4 gg = *(const f32x4 *)(par + C0 + c), bb = *(const f32x4 *)(par + 2 * C0 + c);
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (acc[mf][4 * q + e] - mean) * rstd * gg[e] + bb[e];
+                    *(f32x4 *)(xo + c) = o;
+                }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
-        const float rstd = rsqrtf(var / (float)C0 + eps);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (lane + 64 * u < C0) x[t * C0 + lane + 64 * u] = (acc[u] - mean) * rstd * gr[u] + ber[u];
     }
 }
 
 hipError_t launch_swin_embed(const float *img, const float *w, const float *bias, const float *g, const float *be,
                              float *x, int batch, int chans, int size, int c0, float eps, hipStream_t s) {
-    const size_t T = (size_t)batch * (size / 4) * (size / 4);
-    const unsigned blocks = (unsigned)((T + 31) / 32 < 2048 ? (T + 31) / 32 : 2048);
-    if (c0 <= 64)
-        swin_embed_kernel<1><<<dim3(blocks), dim3(256), 0, s>>>(img, w, bias, g, be, x, batch, chans, size, c0, eps);
-    else if (c0 <= 128)
-        swin_embed_kernel<2><<<dim3(blocks), dim3(256), 0, s>>>(img, w, bias, g, be, x, batch, chans, size, c0, eps);
-    else
-        return hipErrorInvalidValue;
+    if ((chans != 1 && chans != 3) || c0 % 32 || c0 <= 0 || c0 > 128 || size % 4) return hipErrorInvalidValue;
+    const size_t T = (size_t)batch * (size / 4) * (size / 4), tiles = (T + 31) / 32;
+    const unsigned blocks = (unsigned)((tiles + 3) / 4 < 1536 ? (tiles + 3) / 4 : 1536);  // up to six workgroups per CU
+#define OCM_EMBED(CH, CF)                                                                                               \
+    swin_embed_kernel<CH, CF><<<dim3(blocks), dim3(256), 0, s>>>(img, w, bias, g, be, x, batch, size, eps)
+    switch ((chans == 3 ? 4 : 0) + c0 / 32 - 1) {
+        case 0: OCM_EMBED(1, 1); break;
+        case 1: OCM_EMBED(1, 2); break;
+        case 2: OCM_EMBED(1, 3); break;
+        case 3: OCM_EMBED(1, 4); break;
+        case 4: OCM_EMBED(3, 1); break;
+        case 5: OCM_EMBED(3, 2); break;
+        case 6: OCM_EMBED(3, 3); break;
+        default: OCM_EMBED(3, 4); break;
+    }
+#undef OCM_EMBED
     return hipGetLastError();
 }
 
@@ -692,33 +732,34 @@ hipError_t launch_swin_window_attention(int prec, const void *qkv, int ld, void 
 //     per step of 32 hidden units at C = 96), one counted vmcnt wait and one barrier per step;
 //   * epilogue: + b2 + x, fp32, in place. HBM traffic: x once in, once out.
 // ------------------------------------------------------------------------------------------
-template <int CG, int HG>  // C / 32, hidden / 32
-__global__ __launch_bounds__(512, 2) void swin_mlp_x3_kernel(float *__restrict__ x, const float *__restrict__ gam,
+template <int CG, int HG, int NW, int NSTAGE>  // C / 32, hidden / 32, wavefronts per workgroup, LDS stages of the W ring
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void swin_mlp_x3_kernel(float *__restrict__ x, const float *__restrict__ gam,
                                                              const float *__restrict__ bet, const char *__restrict__ w1,
                                                              const float *__restrict__ b1, const char *__restrict__ w2,
                                                              const float *__restrict__ b2, int T, float eps) {
-    constexpr int C = CG * 32, HID = HG * 32, W1B = CG * 4096, STAGE = W1B + C * 128, NSTAGE = 3;
-    constexpr int PIECES = STAGE / 1024, PPW = PIECES / 8, NS = 2 * CG;  // 1-KiB DMA pieces per step / per wave; k slices of 16
-    static_assert(PIECES % 8 == 0, "eight wavefronts share the pieces of a step evenly");
+    constexpr int C = CG * 32, HID = HG * 32, W1B = CG * 4096, STAGE = W1B + C * 128;
+    constexpr int PIECES = STAGE / 1024, PPW = PIECES / NW, NS = 2 * CG;  // 1-KiB DMA pieces per step / per wave; k slices of 16
+    static_assert(PIECES % NW == 0, "the wavefronts share the pieces of a step evenly");
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "one or two steps in flight");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     float *b1s = (float *)(smem + NSTAGE * STAGE);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int tok0 = blockIdx.x * 256 + wave * 32;
+    const int tok0 = (blockIdx.x * NW + wave) * 32;
     const bool live = tok0 + r < T;
     const size_t tok = (size_t)min(tok0 + r, T - 1);
 
-    for (int i = tid; i < HID; i += 512) b1s[i] = b1[i];
+    for (int i = tid; i < HID; i += NW * 64) b1s[i] = b1[i];
 
-    // piece pc = jj * 8 + wave of a step: pieces [0, 4 CG) = W1 (image pc >> 2 = k group, rows (pc & 3) * 8 .. + 7 of the
+    // piece pc = jj * NW + wave of a step: pieces [0, 4 CG) = W1 (image pc >> 2 = k group, rows (pc & 3) * 8 .. + 7 of the
     // step's 32 hidden units), the rest = W2 (rows (pc - 4 CG) * 8 .. + 7 of the C outputs, the step's k group)
     int voff[PPW];
     {
         const int lrow = lane >> 3, slot = lane & 7;
 #pragma unroll
         for (int jj = 0; jj < PPW; ++jj) {
-            const int pc = jj * 8 + wave;
+            const int pc = jj * NW + wave;
             if (pc < 4 * CG) {
                 const int rho = (pc & 3) * 8 + lrow;
                 voff[jj] = rho * (C * 4) + (pc >> 2) * 128 + ((slot ^ ((rho >> 1) & 7)) << 4);
@@ -735,7 +776,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_x3_kernel(float *__restrict__
 #define OCM_MLP_DMA(j, st)                                                                                               \
     do {                                                                                                                 \
         _Pragma("unroll") for (int jj = 0; jj < PPW; ++jj) {                                                             \
-            const int pc = jj * 8 + wave;                                                                                \
+            const int pc = jj * NW + wave;                                                                               \
             char *dst_ = smem + (st) * STAGE + pc * 1024;                                                                \
             if (pc < 4 * CG)                                                                                             \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, (lds_ptr)dst_, 16, voff[jj], (j) * (32 * C * 4), 0, 0);    \
@@ -747,7 +788,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_x3_kernel(float *__restrict__
 #define OCM_MLP_DMA(j, st) (void)0
 #endif
     OCM_MLP_DMA(0, 0);
-    if (HG > 1) OCM_MLP_DMA(1, 1);
+    if (NSTAGE == 3 && HG > 1) OCM_MLP_DMA(1, 1);
 
     // LayerNorm of the wave's rows: lane (r, h) holds channels 16 s + 8 h .. + 7 of token r for every slice s
     bf16x8 xh[NS], xl[NS];
@@ -791,16 +832,16 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_x3_kernel(float *__restrict__
 #pragma unroll
         for (int e = 0; e < 16; ++e) Y[mf][e] = 0.f;
     const int pr = pi_row(r);
-    int sc = 0, si = 2;
+    int sc = 0, si = NSTAGE - 1;
     for (int j = 0; j < HG; ++j) {
-        if (j + 1 < HG)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        if (NSTAGE == 3 && j + 1 < HG)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");  // the younger step may still be on its way
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (j + 2 < HG) OCM_MLP_DMA(j + 2, si);
+        if (j + NSTAGE - 1 < HG) OCM_MLP_DMA(j + NSTAGE - 1, si);  // into the stage of step j - 1: everybody is past it
         const char *W1s = smem + sc * STAGE, *W2s = W1s + W1B;
         f32x16 S;
 #pragma unroll
@@ -861,21 +902,28 @@ bool swin_mlp_fused_supported(int prec, int C, int hidden) { return prec == 2 &&
 hipError_t launch_swin_mlp(int prec, float *x, const float *g, const float *be, const void *w1, const float *b1,
                            const void *w2, const float *b2, size_t T, int C, int hidden, float eps, hipStream_t s) {
     if (!swin_mlp_fused_supported(prec, C, hidden) || T == 0 || T > 0x7fffffffu) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((T + 255) / 256)), block(512);
-    const int lds = 3 * (C / 32 * 4096 + C * 128) + hidden * 4;
+    // C = 96: four wavefronts on a two-stage ring, 50 KiB and 162 registers -> three workgroups per CU;
+    // C = 128: 237 registers -> eight wavefronts, one workgroup per CU, three stages
+    constexpr int NW96 = 4, NS96 = 2, NW128 = 8, NS128 = 3;
+    const int nw = C == 96 ? NW96 : NW128, nst = C == 96 ? NS96 : NS128;
+    const dim3 grid((unsigned)((T + nw * 32 - 1) / (nw * 32))), block(nw * 64);
+    const int lds = nst * (C / 32 * 4096 + C * 128) + hidden * 4;
     static unsigned long long optin[2] = {0, 0};
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-    const void *kern = C == 96 ? (const void *)swin_mlp_x3_kernel<3, 12> : (const void *)swin_mlp_x3_kernel<4, 16>;
+    const void *kern = C == 96 ? (const void *)swin_mlp_x3_kernel<3, 12, NW96, NS96>
+                               : (const void *)swin_mlp_x3_kernel<4, 16, NW128, NS128>;
     unsigned long long &mask = optin[C == 96 ? 0 : 1];
     if (!(mask >> (dev & 63) & 1)) {
         if (hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); e != hipSuccess) return e;
         mask |= 1ull << (dev & 63);
     }
     if (C == 96)
-        swin_mlp_x3_kernel<3, 12><<<grid, block, lds, s>>>(x, g, be, (const char *)w1, b1, (const char *)w2, b2, (int)T, eps);
+        swin_mlp_x3_kernel<3, 12, NW96, NS96><<<grid, block, lds, s>>>(x, g, be, (const char *)w1, b1, (const char *)w2, b2,
+                                                                        (int)T, eps);
     else
-        swin_mlp_x3_kernel<4, 16><<<grid, block, lds, s>>>(x, g, be, (const char *)w1, b1, (const char *)w2, b2, (int)T, eps);
+        swin_mlp_x3_kernel<4, 16, NW128, NS128><<<grid, block, lds, s>>>(x, g, be, (const char *)w1, b1, (const char *)w2, b2,
+                                                                          (int)T, eps);
     return hipGetLastError();
 }
 
