@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCM_ABI_VERSION 6
+#define OCM_ABI_VERSION 7
 
 enum {
     OCM_OK = 0,
@@ -258,6 +258,18 @@ int ocm_op_attention_probs(int32_t precision, const void *q, const void *k, cons
 int ocm_op_attention_rows(int32_t precision, const void *q, const void *k, const int32_t *query_rows,
                           int32_t n_rows, float *rows, int32_t batch, int32_t n_tokens, int32_t heads, float scale,
                           void *stream);
+
+/* The qkv projection, attention and probabilities for heads of `head_dim` channels: 64 (identical to the entry points
+ * above), or 128 in OCM_PREC_BF16X3 — the encoder the reference's build_model() constructs
+ * (Self-supervised_segmentation/model.py:93-103: embed_dim 384, 3 heads). q / k are then [B*H][n_pad][128] and vt
+ * [B*H][128][n_pad] split pairs, ctx [B][N][H*128]. Any other combination returns OCM_EINVAL (an engine handle runs such
+ * heads on its generic fp32 attention kernel). */
+int ocm_op_qkv_proj_hd(int32_t precision, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
+                       float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, void *stream);
+int ocm_op_attention_hd(int32_t precision, const void *q, const void *k, const void *vt, void *ctx, float *lse2,
+                        int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, float scale, void *stream);
+int ocm_op_attention_probs_hd(int32_t precision, const void *q, const void *k, const float *lse2, float *attn,
+                              int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, float scale, void *stream);
 
 /* compute_attention (utils.py:229-235) on device: attn fp32 [B][H][N][N] ->
  * maps fp32 [H][hf*p][wf*p] = nearest-neighbour x p upsample of attn[b, :, query, 1:]. */

@@ -162,6 +162,55 @@ def test_attention_x3(lib, dev, B, N, H, sharp):
     assert (rows.double() - pref.reshape(B, H, N, N)[:, :, rows_idx.long(), 1:]).abs().max().item() < 2e-5 * es
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 65, 3), (1, 197, 3), (3, 300, 2), (1, 32, 1)])
+@pytest.mark.parametrize("sharp", [1.0, 2.0])
+def test_attention_x3_128_wide_heads(lib, dev, B, N, H, sharp):
+    """The encoder the reference's build_model() constructs (model.py:93-103) has 3 heads of 128 channels: qkv projection,
+    attention and probabilities on the split-bf16 MFMA kernels templated on the head width, against float64 torch."""
+    HD, D = 128, H * 128
+    a, w, bias = _rand((B * N, D), dev, 70), _rand((3 * D, D), dev, 71, 0.05 * sharp), _rand((3 * D,), dev, 72, 0.1)
+    npad = lib.ocm_n_pad_prec(X3, N)
+    q = torch.full((B * H, npad, HD), -1, dtype=torch.int32, device=dev)  # 0xFFFF pairs: NaN wherever nothing is written
+    k = torch.full_like(q, -1)
+    vt = torch.full((B * H, HD, npad), -1, dtype=torch.int32, device=dev)
+    qkv32 = torch.empty((3, B, H, N, HD), device=dev)
+    a_s, w_s = to_operand(a, X3), to_operand(w, X3)
+    _ok(lib, lib.ocm_op_qkv_proj_hd(X3, _p(a_s), _p(w_s), _p(bias), _p(q), _p(k), _p(vt), _p(qkv32), B, N, H, HD, _s()))
+    ref = (a.double() @ w.double().t() + bias.double()).reshape(B, N, 3, H, HD).permute(2, 0, 3, 1, 4)
+    tol = 3e-5 * max(1.0, math.sqrt(D) / 8) * sharp
+    assert (qkv32.double() - ref).abs().max().item() < tol
+    assert (from_split(q)[:, :N].double() - ref[0].reshape(B * H, N, HD)).abs().max().item() < tol
+    assert (from_split(k)[:, :N].double() - ref[1].reshape(B * H, N, HD)).abs().max().item() < tol
+    assert (from_split(vt)[:, :, :N].double() - ref[2].reshape(B * H, N, HD).transpose(1, 2)).abs().max().item() < tol
+    # attention on what the projection wrote (padding rows / columns still NaN pairs: they must not reach a result),
+    # against float64 attention of exactly those operand values
+    qd, kd = from_split(q)[:, :N].double(), from_split(k)[:, :N].double()
+    vd = from_split(vt)[:, :, :N].double().transpose(1, 2)
+    scale = HD ** -0.5
+    s = (qd @ kd.transpose(1, 2)) * scale
+    pref = s.softmax(-1)
+    oref = (pref @ vd).reshape(B, H, N, HD).permute(0, 2, 1, 3).reshape(B, N, D)
+    ctx = torch.full((B, N, D), -1, dtype=torch.int32, device=dev)
+    lse = torch.empty((B * H, N), device=dev)
+    _ok(lib, lib.ocm_op_attention_hd(X3, _p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, HD, scale, _s()))
+    # as in test_attention_x3: a score is a sum of products of 2^-17-accurate operands, so its absolute error (and the relative
+    # error of every probability) grows with the operands' magnitude: |q| |k| ~ 1 .. 4 here
+    es = max(1.0, float(qd.std() * kd.std())) * max(1.0, float(vd.abs().max()) / 4)
+    assert (lse.double() - torch.logsumexp(s, -1) / math.log(2.0)).abs().max().item() < 1e-4 * es
+    got = from_split(ctx).double()
+    assert torch.isfinite(got).all()
+    assert (got - oref).abs().max().item() < 4e-5 * es
+    attn = torch.full((B, H, N, N), float("nan"), device=dev)
+    _ok(lib, lib.ocm_op_attention_probs_hd(X3, _p(q), _p(k), _p(lse), _p(attn), B, N, H, HD, scale, _s()))
+    assert (attn.reshape(B * H, N, N).double() - pref).abs().max().item() < 2e-5 * es
+    lse2 = torch.empty_like(lse)
+    _ok(lib, lib.ocm_op_attention_hd(X3, _p(q), _p(k), _p(vt), None, _p(lse2), B, N, H, HD, scale, _s()))
+    assert torch.equal(lse, lse2)
+    # other precisions keep the generic fp32 kernel inside an engine handle; the operator says so
+    assert lib.ocm_op_attention_hd(_lib.OCM_PREC_BF16, _p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, HD, scale, _s()) == _lib.OCM_EINVAL
+    assert lib.ocm_op_attention_hd(X3, _p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, 96, scale, _s()) == _lib.OCM_EINVAL
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp32", "bf16x3"])
 @pytest.mark.parametrize("M,D,K", [(1000, 384, 384), (12608, 384, 1536), (70, 128, 192), (333, 256, 512), (64, 256, 64)])
 def test_linear_resid_ln_equals_linear_then_layernorm(lib, dev, prec, M, D, K):

@@ -184,4 +184,9 @@ def test_reference_build_model_runs_with_128_channel_heads(dev):
     assert float((qkvs[0].cpu() - oqkv[0]).abs().max()) <= 1e-4 * float(oqkv[0].abs().max())
     assert torch.equal(enc.get_last_selfattention(x.to(dev)), attns[0])
     rows = enc.get_last_attention_rows(x.to(dev), torch.tensor([0, 7], dtype=torch.int32, device=dev))
-    assert torch.equal(rows, attns[0][:, :, [0, 7], 1:])
+    # 128-wide heads run the split-bf16 MFMA attention kernels like 64-wide ones: the selected rows come from their own
+    # fp32 dot-product kernel (never the (H,N,N) matrix), so they match the matrix to rounding, as in test_model_gpu.py
+    assert float((rows - attns[0][:, :, [0, 7], 1:]).abs().max()) < 2e-5
+    # the fp32 and bf16 modes keep the generic fp32 attention for such heads; the attention maps agree across modes
+    a32 = enc.set_precision("fp32").get_last_selfattention(x.to(dev))
+    assert float((a32.cpu() - oattn[0]).abs().max()) <= 1e-5

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OCM_VIT_LIB lets kernel experiments A/B two builds of the same ABI; the default is the in-tree build.
 LIB_PATH = os.environ.get("OCM_VIT_LIB") or os.path.join(_HERE, "libocm_vit.so")
 
-OCM_ABI_VERSION = 6
+OCM_ABI_VERSION = 7
 OCM_OK, OCM_EINVAL, OCM_ESTATE, OCM_EHIP, OCM_ENOMEM, OCM_ENAME = 0, 1, 2, 3, 4, 5
 
 OCM_PREC_BF16 = 0
@@ -128,6 +128,9 @@ SIGNATURES = {
     "ocm_n_pad": (_i32, [_i32]),
     "ocm_op_qkv_proj": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "ocm_op_attention": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "ocm_op_qkv_proj_hd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ocm_op_attention_hd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "ocm_op_attention_probs_hd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "ocm_op_attention_probs": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "ocm_op_attention_rows": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp]),
     "ocm_op_attention_map": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

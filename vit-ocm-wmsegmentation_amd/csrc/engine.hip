@@ -129,7 +129,9 @@ struct BlockP {
 struct ocm_vit {
     ocm_vit_config cfg;
     int D, H, L, M, p, C, Kpe;
-    int hd;    // head_dim: 64 runs the MFMA attention kernels, anything else the generic fp32 attention (model.py:96-97)
+    int hd;    // head_dim: 64 (and 128 in split-bf16 precision, model.py:96-97) runs the MFMA attention kernels, anything else the
+               // generic fp32 attention
+    bool mfma_heads() const { return hd == 64 || (hd == 128 && prec == 2); }
     int prec;  // 0 = bf16 operands, 1 = fp32 operands, 2 = split-bf16 pairs (element size esz of matrices / activations)
     size_t esz;
     std::vector<Param> params;
@@ -339,8 +341,8 @@ extern "C" int ocm_vit_params_ready(const ocm_vit_t *h) {
 struct Workspace {  // E = bf16 (OCM_PREC_BF16) or float (OCM_PREC_FP32)
     float *x;     // [T][D]   fp32 residual stream
     void *xn;     // [T][D] E LayerNorm output (GEMM A operand)
-    void *q, *k;  // [B*H][n_pad][64] E
-    void *vt;     // [B*H][64][n_pad] E
+    void *q, *k;  // [B*H][n_pad][hd] E
+    void *vt;     // [B*H][hd][n_pad] E
     void *ctx;    // [T][D] E attention output, heads merged
     void *hid;    // [T][M] E GELU(fc1)
     float *lse;   // [B*H][N]
@@ -371,10 +373,10 @@ static Workspace carve(const ocm_vit *h, int batch, int n, char *base) {
     const size_t base_off = off;
     w.q = w.k = w.vt = nullptr;
     w.qkv32 = nullptr;
-    if (h->hd == 64) {
-        w.q = take(BH * np * 64 * e);
-        w.k = take(BH * np * 64 * e);
-        w.vt = take(BH * np * 64 * e);
+    if (h->mfma_heads()) {
+        w.q = take(BH * np * h->hd * e);
+        w.k = take(BH * np * h->hd * e);
+        w.vt = take(BH * np * h->hd * e);
     } else {
         w.qkv32 = (float *)take(3 * T * h->D * 4);
     }
@@ -429,28 +431,28 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     if (!xn_ready) { PROF(OCM_K_LN, s); HIP_TRY(launch_layernorm(x, h->ptr<float>(bp.ln1_g), h->ptr<float>(bp.ln1_b), w.xn, lnk, T, D, eps, s)); }
     // a block that stops after its probabilities (get_last_selfattention) and returns no qkv never reads V
     const bool want_v = !(attn_only && !out_qkv);
-    if (h->hd != 64) {  // generic heads: fp32 qkv tensor -> fp32 FMA attention
+    if (!h->mfma_heads()) {  // generic heads: fp32 qkv tensor -> fp32 FMA attention
         float *qkv = out_qkv ? out_qkv : w.qkv32;
         { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_w), h->ptr<float>(bp.qkv_b), nullptr, nullptr, nullptr, qkv, batch, n, np, H, h->hd, want_v, s)); }
         { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention_generic(pc, qkv, attn_only ? nullptr : w.ctx, out_attn, query_rows, n_rows, out_rows, batch, n, H, h->hd, scale, s)); }
         if (attn_only) return OCM_OK;
     } else {
     void *vt_dst = want_v ? w.vt : nullptr;
-    { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, vt_dst, out_qkv, batch, n, np, H, 64, want_v, s)); }
+    { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_w), h->ptr<float>(bp.qkv_b), w.q, w.k, vt_dst, out_qkv, batch, n, np, H, h->hd, want_v, s)); }
     // selected query rows: a slice of the probabilities when those are materialised for this block anyway,
     // else their own fp32 dot-product kernel (never the (H,N,N) matrix)
-    if (out_rows && !out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s)); }
+    if (out_rows && !out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s, h->hd)); }
     if (attn_only) {
         if (out_attn) {
-            { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s)); }
-            { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
+            { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s, h->hd)); }
+            { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s, h->hd)); }
             if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
         }
         return OCM_OK;
     }
-    { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s)); }
+    { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s, h->hd)); }
     if (out_attn) {
-        { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
+        { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s, h->hd)); }
         if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
     }
     }
@@ -495,26 +497,26 @@ static int run_block_folded(const ocm_vit *h, int i, const Workspace &w, float *
     ln2.stats = st_mid, ln2.c = h->ptr<float>(bp.fc1_c), ln2.d = h->ptr<float>(bp.fc1_d), ln2.inv_dim = 1.0f / D, ln2.eps = h->cfg.ln_eps;
     ln1.nslot = ln2.nslot = D / 64;
     const bool want_v = !(attn_only && !out_qkv);
-    if (h->hd != 64) {
+    if (!h->mfma_heads()) {
         float *qkv = out_qkv ? out_qkv : w.qkv32;
         { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_wf), nullptr, nullptr, nullptr, nullptr, qkv, batch, n, np, H, h->hd, want_v, s, ln1)); }
         { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention_generic(pc, qkv, attn_only ? nullptr : w.ctx, out_attn, query_rows, n_rows, out_rows, batch, n, H, h->hd, scale, s)); }
         if (attn_only) return OCM_OK;
     } else {
         void *vt_dst = want_v ? w.vt : nullptr;
-        { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_wf), nullptr, w.q, w.k, vt_dst, out_qkv, batch, n, np, H, 64, want_v, s, ln1)); }
-        if (out_rows && !out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s)); }
+        { PROF(OCM_K_QKV, s); HIP_TRY(launch_qkv(pc, w.xn, h->ptr<char>(bp.qkv_wf), nullptr, w.q, w.k, vt_dst, out_qkv, batch, n, np, H, h->hd, want_v, s, ln1)); }
+        if (out_rows && !out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s, h->hd)); }
         if (attn_only) {
             if (out_attn) {
-                { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s)); }
-                { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
+                { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s, h->hd)); }
+                { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s, h->hd)); }
                 if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
             }
             return OCM_OK;
         }
-        { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s)); }
+        { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s, h->hd)); }
         if (out_attn) {
-            { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s)); }
+            { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s, h->hd)); }
             if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
         }
     }
@@ -806,37 +808,75 @@ extern "C" int ocm_op_linear_resid_ln(int32_t precision, const void *a, const vo
     return OCM_OK;
 }
 
-extern "C" int ocm_op_qkv_proj(int32_t precision, const void *a, const void *w, const float *bias, void *q, void *k,
-                               void *vt, float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads, void *stream) {
+static int op_qkv_proj(int32_t precision, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
+                       float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, void *stream) {
     int pc = 0, rc = prec_of(precision, &pc);
     if (rc) return rc;
     if (!a || !w || !bias || !q || !k || !vt) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_qkv(pc, a, w, bias, q, k, vt, qkv_f32, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, 64, true, (hipStream_t)stream));
+    if (head_dim != 64 && !(head_dim == 128 && pc == 2))
+        return fail(OCM_EINVAL, "head_dim %d: operand copies exist for 64-wide heads, and for 128-wide heads in split-bf16 precision", head_dim);
+    HIP_TRY(launch_qkv(pc, a, w, bias, q, k, vt, qkv_f32, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, head_dim, true,
+                       (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_qkv_proj(int32_t precision, const void *a, const void *w, const float *bias, void *q, void *k,
+                               void *vt, float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads, void *stream) {
+    return op_qkv_proj(precision, a, w, bias, q, k, vt, qkv_f32, batch, n_tokens, heads, 64, stream);
+}
+
+extern "C" int ocm_op_qkv_proj_hd(int32_t precision, const void *a, const void *w, const float *bias, void *q, void *k,
+                                  void *vt, float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads,
+                                  int32_t head_dim, void *stream) {
+    return op_qkv_proj(precision, a, w, bias, q, k, vt, qkv_f32, batch, n_tokens, heads, head_dim, stream);
+}
+
+static int op_attention(int32_t precision, const void *q, const void *k, const void *vt, void *ctx, float *lse2,
+                        int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, float scale, void *stream) {
+    int pc = 0, rc = prec_of(precision, &pc);
+    if (rc) return rc;
+    if (!q || !k || !vt || (!ctx && !lse2)) return fail(OCM_EINVAL, "null argument");
+    if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
+    if (head_dim != 64 && !(head_dim == 128 && pc == 2))
+        return fail(OCM_EINVAL, "head_dim %d: the MFMA attention is built for 64-wide heads, and for 128-wide heads in split-bf16 precision", head_dim);
+    HIP_TRY(launch_attention(pc, q, k, vt, ctx, lse2, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, scale,
+                             (hipStream_t)stream, head_dim));
+    return OCM_OK;
+}
+
+static int op_attention_probs(int32_t precision, const void *q, const void *k, const float *lse2, float *attn, int32_t batch,
+                              int32_t n_tokens, int32_t heads, int32_t head_dim, float scale, void *stream) {
+    int pc = 0, rc = prec_of(precision, &pc);
+    if (rc) return rc;
+    if (!q || !k || !lse2 || !attn) return fail(OCM_EINVAL, "null argument");
+    if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
+    if (head_dim != 64 && !(head_dim == 128 && pc == 2)) return fail(OCM_EINVAL, "head_dim %d not built in this precision", head_dim);
+    HIP_TRY(launch_attention_probs(pc, q, k, lse2, attn, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, scale,
+                                   (hipStream_t)stream, head_dim));
     return OCM_OK;
 }
 
 extern "C" int ocm_op_attention(int32_t precision, const void *q, const void *k, const void *vt, void *ctx, float *lse2,
                                 int32_t batch, int32_t n_tokens, int32_t heads, float scale, void *stream) {
-    int pc = 0, rc = prec_of(precision, &pc);
-    if (rc) return rc;
-    if (!q || !k || !vt) return fail(OCM_EINVAL, "null argument");
-    if (!ctx && !lse2) return fail(OCM_EINVAL, "nothing to compute: ctx and lse2 are both null");
-    if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_attention(pc, q, k, vt, ctx, lse2, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, scale,
-                             (hipStream_t)stream));
-    return OCM_OK;
+    return op_attention(precision, q, k, vt, ctx, lse2, batch, n_tokens, heads, 64, scale, stream);
+}
+
+extern "C" int ocm_op_attention_hd(int32_t precision, const void *q, const void *k, const void *vt, void *ctx, float *lse2,
+                                   int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, float scale,
+                                   void *stream) {
+    return op_attention(precision, q, k, vt, ctx, lse2, batch, n_tokens, heads, head_dim, scale, stream);
 }
 
 extern "C" int ocm_op_attention_probs(int32_t precision, const void *q, const void *k, const float *lse2, float *attn,
                                       int32_t batch, int32_t n_tokens, int32_t heads, float scale, void *stream) {
-    int pc = 0, rc = prec_of(precision, &pc);
-    if (rc) return rc;
-    if (!q || !k || !lse2 || !attn) return fail(OCM_EINVAL, "null argument");
-    if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    HIP_TRY(launch_attention_probs(pc, q, k, lse2, attn, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, scale,
-                                   (hipStream_t)stream));
-    return OCM_OK;
+    return op_attention_probs(precision, q, k, lse2, attn, batch, n_tokens, heads, 64, scale, stream);
+}
+
+extern "C" int ocm_op_attention_probs_hd(int32_t precision, const void *q, const void *k, const float *lse2, float *attn,
+                                         int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, float scale,
+                                         void *stream) {
+    return op_attention_probs(precision, q, k, lse2, attn, batch, n_tokens, heads, head_dim, scale, stream);
 }
 
 extern "C" int ocm_op_attention_rows(int32_t precision, const void *q, const void *k, const int32_t *query_rows,

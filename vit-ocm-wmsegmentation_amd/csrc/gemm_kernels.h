@@ -641,7 +641,7 @@ hipError_t launch_resid_ln_e(const E *a, const E *w, const float *bias, const fl
 template <class E>
 struct EpiQK {
     const float *bias;
-    E *q, *k;      // head-major operand copies (head_dim 64 only), or nullptr
+    E *q, *k;      // head-major operand copies [B*H][n_pad][hd] (hd 64, or 128 as split pairs), or nullptr
     float *qkv32;  // optional (3,B,H,N,hd) fp32, or nullptr
     int M, ntok, npad, H, D, B, hd;
     int wt = 0;  // write-through stores for q / k
@@ -684,7 +684,7 @@ struct EpiQK {
                 }
             }
             if (base) {
-                char *rowp = (char *)base + ((int64_t)(b * H + head) * npad + t) * 64 * (int)sizeof(E);
+                char *rowp = (char *)base + ((int64_t)(b * H + head) * npad + t) * hd * (int)sizeof(E);
                 if (Elem<E>::EPW == 8) {
                     if (wt)
                         store_act_wt((E *)nullptr, rowp, d, v0, v1);
@@ -713,7 +713,7 @@ struct EpiQK {
 template <class E>
 struct EpiVt {
     const float *bias;
-    E *vt;  // key-contiguous V^T (head_dim 64 only); a null vt with a non-null qkv32 still computes the V third
+    E *vt;  // key-contiguous V^T [B*H][hd][n_pad] (hd 64, or 128 as split pairs); a null vt with a non-null qkv32 still computes the V third
     float *qkv32;
     int M, ntok, npad, H, D, B, hd;
     bool want_v;  // compute the V third at all
@@ -746,7 +746,7 @@ struct EpiVt {
                 const f32x2 cd = coltab[row];
                 v = fmaf(rstd, fmaf(-mu, cd[0], v), cd[1]);
             }
-            if (vt) store_act1((E *)nullptr, (char *)vt + ((int64_t)(b * H + head) * 64 + d) * npad * (int)sizeof(E), t, v);
+            if (vt) store_act1((E *)nullptr, (char *)vt + ((int64_t)(b * H + head) * hd + d) * npad * (int)sizeof(E), t, v);
             if (qkv32) qkv32[((((int64_t)2 * B + b) * H + head) * ntok + t) * hd + d] = v;
         }
     }
@@ -848,7 +848,8 @@ hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E
                                int n_tokens, int n_pad, int heads, int head_dim, bool want_v, hipStream_t s,
                                const LnFold &ln) {
     const int D = heads * head_dim, M = batch * n_tokens;
-    if (head_dim != 64 && (q || k || vt)) return hipErrorInvalidValue;  // operand copies exist for 64-channel heads only
+    // operand copies exist for 64-channel heads, and for 128-channel heads as split pairs
+    if (head_dim != 64 && !(head_dim == 128 && Elem<E>::MODE == 2) && (q || k || vt)) return hipErrorInvalidValue;
     if (head_dim % 8) return hipErrorInvalidValue;                      // a lane's 8 columns stay inside one head
     RowLoader<E> al{a, D};
     EpiQK<E> eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch, head_dim};

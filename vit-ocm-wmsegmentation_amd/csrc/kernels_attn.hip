@@ -857,14 +857,17 @@ extern "C" int ocm_debug_stamps_attn(unsigned long long *host, int n) {
 //     are resident at once (the 64 KiB / 198-register kernel ran them in one and a half rounds of two).
 // Padding keys of the last tile: their K rows are inside the buffer (scores overwritten with -inf), their V^T columns
 // are zeroed in LDS after the tile has landed (the qkv epilogue never writes them; 0 * garbage must not be NaN).
-template <bool WANT_O, int NW, int WPS>
+// HD = head width: 64 (the DINO ViTs), or 128 (the reference's SimMIM encoder, model.py:93-103) on a two-stage ring of
+// 32 KiB stages (K: four [32 keys][128 B] images, V^T: [128 d][128 B]) with twice the Q fragments and context accumulators.
+template <bool WANT_O, int NW, int WPS, int HD = 64, int NSTAGE = 3>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const char *__restrict__ Q,
                                                                        const char *__restrict__ Kk,
                                                                        const char *__restrict__ Vt, char *__restrict__ ctx,
                                                                        float *__restrict__ lse2, int N, int npad, int H,
                                                                        float scale2, int wt) {
-    constexpr int NSTAGE = 3, STAGE = 16384, KP = 8 / NW, VP = WANT_O ? 8 / NW : 0, LPS = KP + VP;
-    static_assert(NW == 4 || NW == 8, "8 pieces of 1 KiB per operand and tile");
+    constexpr int KB = HD * 128, STAGE = 2 * KB, KP = HD / 8 / NW, VP = WANT_O ? HD / 8 / NW : 0, LPS = KP + VP;  // KB: K bytes of a 32-key tile
+    constexpr int NQ = HD / 16, ND = HD / 32;  // k slices of the score product, 32-channel blocks of the context
+    static_assert((NW == 4 || NW == 8) && (HD == 64 || HD == 128) && (NSTAGE == 2 || NSTAGE == 3), "HD / 8 pieces of 1 KiB per operand and tile");
     __shared__ __attribute__((aligned(1024))) char smem[NSTAGE * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -875,17 +878,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
     xcd_remap2(qblk, bh);
     const int q0 = (qblk * NW + wave) * 32;
     const bool active = q0 < N;  // wave-uniform
-    const char *Qb = Q + (int64_t)bh * npad * 256;
-    const char *Kb = Kk + (int64_t)bh * npad * 256;
-    const char *Vb = Vt + (int64_t)bh * 64 * npad * 4;
+    const char *Qb = Q + (int64_t)bh * npad * (HD * 4);
+    const char *Kb = Kk + (int64_t)bh * npad * (HD * 4);
+    const char *Vb = Vt + (int64_t)bh * HD * npad * 4;
     const int ntiles = (N + 31) >> 5;
 
     // Q^T as the B operand: issued first, so the counted waits below cover it too (vmcnt retires in order)
-    bf16x8 qh[4], ql[4];
+    bf16x8 qh[NQ], ql[NQ];
     {
-        const char *qp = Qb + (int64_t)min(q0 + r, N - 1) * 256;
+        const char *qp = Qb + (int64_t)min(q0 + r, N - 1) * (HD * 4);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NQ; ++s) {
             const char *p = qp + (s >> 1) * 128 + ((s & 1) * 16 + 8 * h) * 2;
             qh[s] = *(const bf16x8 *)p;
             ql[s] = *(const bf16x8 *)(p + 64);
@@ -899,7 +902,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
 #pragma unroll
         for (int j = 0; j < KP; ++j) {
             const int pc = j * NW + wave, rho = (pc & 3) * 8 + lrow;
-            voffK[j] = rho * 256 + (pc >> 2) * 128 + ((slot ^ ((rho >> 1) & 7)) << 4);
+            voffK[j] = rho * (HD * 4) + (pc >> 2) * 128 + ((slot ^ ((rho >> 1) & 7)) << 4);
         }
 #pragma unroll
         for (int j = 0; j < VP; ++j) {
@@ -909,16 +912,16 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) void *lds_ptr;
-    const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, (unsigned)(npad * 256), 0x00020000);
-    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, (unsigned)(64 * npad * 4), 0x00020000);
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, (unsigned)(npad * HD * 4), 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, (unsigned)(HD * npad * 4), 0x00020000);
 #define OCM_ATTN_DMA(t, st)                                                                                              \
     do {                                                                                                                 \
         char *st_ = smem + (st) * STAGE;                                                                                 \
         _Pragma("unroll") for (int j = 0; j < KP; ++j)                                                                   \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(st_ + (j * NW + wave) * 1024), 16, voffK[j],       \
-                                                     (t) * 8192, 0, 0);                                                  \
+                                                     (t) * (32 * HD * 4), 0, 0);                                                  \
         _Pragma("unroll") for (int j = 0; j < VP; ++j)                                                                   \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(st_ + 8192 + (j * NW + wave) * 1024), 16, voffV[j], \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(st_ + KB + (j * NW + wave) * 1024), 16, voffV[j], \
                                                      (t) * 128, 0, 0);                                                   \
     } while (0)
 #else
@@ -926,24 +929,26 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
 #endif
 
     OCM_ATTN_DMA(0, 0);
-    if (ntiles > 1) OCM_ATTN_DMA(1, 1);
+    if (NSTAGE == 3 && ntiles > 1) OCM_ATTN_DMA(1, 1);
     // Q and the first two tiles have landed before the loop (builtin, not asm: hipcc's own wait-count bookkeeping must
     // see that the Q registers are complete, or it re-waits for them inside the loop with a count that also covers the
     // tile in flight). 0x0F70 = vmcnt(0), expcnt / lgkmcnt untouched.
     __builtin_amdgcn_s_waitcnt(0x0F70);
     ASTAMP(1);  // Q and the first two tiles landed
 
-    f32x16 O[2];
+    f32x16 O[ND];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) O[0][e] = O[1][e] = 0.f;
+    for (int db = 0; db < ND; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[db][e] = 0.f;
     float m = -INFINITY, l = 0.f;
     const int pr = pi_row(r);
     const int first_pad = N - (ntiles - 1) * 32;  // valid keys of the last tile (1..32)
-    int sc = 0, si = 2;                           // stage computed next / filled next
+    int sc = 0, si = NSTAGE - 1;                  // stage computed next / filled next
 
     for (int kt = 0; kt < ntiles; ++kt) {
         // own DMAs of tile kt have landed once at most the younger tile kt+1 is pending
-        if (kt + 1 < ntiles)
+        if (NSTAGE == 3 && kt + 1 < ntiles)
             OCM_VMCNT_ATTN(LPS);
         else
             OCM_VMCNT_ATTN(0);
@@ -954,22 +959,24 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
         asm volatile("" ::: "memory");
         ASTAMP(2 + kt);  // barrier of tile kt passed
 #if !defined(OCM_ABL) || OCM_ABL != 5  // ablation 5: no staging after the prologue
-        if (kt + 2 < ntiles) OCM_ATTN_DMA(kt + 2, si);  // into the stage of tile kt-1: everybody is past it
+        if (kt + NSTAGE - 1 < ntiles) OCM_ATTN_DMA(kt + NSTAGE - 1, si);  // into the stage of tile kt-1: everybody is past it
 #endif
-        char *Kt = smem + sc * STAGE, *Vtile = Kt + 8192;
+        char *Kt = smem + sc * STAGE, *Vtile = Kt + KB;
         if (WANT_O && kt + 1 == ntiles && first_pad < 32) {  // zero the V^T columns of the padding keys (wave-uniform)
             if (tid < 256) {
-                const int d = tid >> 2, kc = tid & 3;
+                const int kc = tid & 3;
                 if (kc * 8 + 8 > first_pad) {
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        bf16x8 *p = (bf16x8 *)(Vtile + lds_off(d, half * 4 + kc));
-                        bf16x8 t = *p;
+                    for (int d = tid >> 2; d < HD; d += 64)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            if (kc * 8 + e >= first_pad) t[e] = (bf16)0.f;
-                        *p = t;
-                    }
+                        for (int half = 0; half < 2; ++half) {
+                            bf16x8 *p = (bf16x8 *)(Vtile + lds_off(d, half * 4 + kc));
+                            bf16x8 t = *p;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (kc * 8 + e >= first_pad) t[e] = (bf16)0.f;
+                            *p = t;
+                        }
                 }
             }
             lds_barrier();
@@ -983,7 +990,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
 #pragma unroll
             for (int e = 0; e < 16; ++e) S[e] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NQ; ++s) {
                 const char *kp = Kt + (s >> 1) * 4096;
                 const bf16x8 kh = *(const bf16x8 *)(kp + lds_off(pr, (s & 1) * 2 + h));
                 const bf16x8 kl = *(const bf16x8 *)(kp + lds_off(pr, 4 + (s & 1) * 2 + h));
@@ -1012,10 +1019,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
             if (WANT_O) {
                 if (__any(alpha != 1.0f)) {  // the running max moved somewhere in this wave
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        O[0][e] *= alpha;
-                        O[1][e] *= alpha;
-                    }
+                    for (int e = 0; e < 16; ++e)
+#pragma unroll
+                        for (int db = 0; db < ND; ++db) O[db][e] *= alpha;
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
@@ -1028,7 +1034,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
                         pl[e] = (bf16)(pv - (float)t);
                     }
 #pragma unroll
-                    for (int db = 0; db < 2; ++db) {
+                    for (int db = 0; db < ND; ++db) {
                         const char *vp = Vtile + db * 32 * 128;
                         const bf16x8 vh = *(const bf16x8 *)(vp + lds_off(r, 2 * s2 + h));
                         const bf16x8 vl = *(const bf16x8 *)(vp + lds_off(r, 4 + 2 * s2 + h));
@@ -1051,9 +1057,9 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
         if (WANT_O) {
             const float inv = 1.0f / lt;
             const int b = bh / H, head = bh - b * H;
-            char *dst = ctx + ((int64_t)b * N + qrow) * (H * 64) * 4 + head * 256;
+            char *dst = ctx + ((int64_t)b * N + qrow) * (H * HD) * 4 + head * (HD * 4);
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < ND; ++db)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 o;
@@ -1249,6 +1255,7 @@ __global__ __launch_bounds__(512, 2) void attn_small_x3_kernel(const char *__res
     }
 }
 
+template <int HD>
 __global__ __launch_bounds__(256) void attn_probs_x3_kernel(const char *__restrict__ Q, const char *__restrict__ Kk,
                                                             const float *__restrict__ lse2, float *__restrict__ attn,
                                                             int N, int npad, float scale2) {
@@ -1258,25 +1265,26 @@ __global__ __launch_bounds__(256) void attn_probs_x3_kernel(const char *__restri
     xcd_remap2(qblk, bh);
     const int q0 = (qblk * 4 + wave) * 32;
     if (q0 >= N) return;  // no barriers in this kernel
-    const char *Qb = Q + (int64_t)bh * npad * 256;
-    const char *Kb = Kk + (int64_t)bh * npad * 256;
-    auto loadrow = [&](const char *base, int row, bf16x8(&hi)[4], bf16x8(&lo)[4]) {
-        const char *rp = base + (int64_t)row * 256;
+    constexpr int NQ = HD / 16;
+    const char *Qb = Q + (int64_t)bh * npad * (HD * 4);
+    const char *Kb = Kk + (int64_t)bh * npad * (HD * 4);
+    auto loadrow = [&](const char *base, int row, bf16x8(&hi)[NQ], bf16x8(&lo)[NQ]) {
+        const char *rp = base + (int64_t)row * (HD * 4);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NQ; ++s) {
             const char *p = rp + (s >> 1) * 128 + ((s & 1) * 16 + 8 * h) * 2;
             hi[s] = *(const bf16x8 *)p;
             lo[s] = *(const bf16x8 *)(p + 64);
         }
     };
-    bf16x8 qh[4], ql[4];
+    bf16x8 qh[NQ], ql[NQ];
     loadrow(Qb, min(q0 + r, N - 1), qh, ql);
     float lr[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) lr[e] = lse2[(int64_t)bh * N + min(q0 + acc_row32(e, h), N - 1)];
     float *out = attn + (int64_t)bh * N * N;
     const int ktiles = (N + 31) >> 5;
-    bf16x8 kh[4], kl[4], nh[4], nl[4];
+    bf16x8 kh[NQ], kl[NQ], nh[NQ], nl[NQ];
     loadrow(Kb, min(r, N - 1), kh, kl);
     for (int kt = 0; kt < ktiles; ++kt) {
         if (kt + 1 < ktiles) loadrow(Kb, min((kt + 1) * 32 + r, N - 1), nh, nl);
@@ -1284,7 +1292,7 @@ __global__ __launch_bounds__(256) void attn_probs_x3_kernel(const char *__restri
 #pragma unroll
         for (int e = 0; e < 16; ++e) S[e] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) S = mfma32x3(qh[s], ql[s], kh[s], kl[s], S);  // rows = queries, col (lane) = key
+        for (int s = 0; s < NQ; ++s) S = mfma32x3(qh[s], ql[s], kh[s], kl[s], S);  // rows = queries, col (lane) = key
         const int key = kt * 32 + r;
         if (key < N) {
 #pragma unroll
@@ -1294,7 +1302,7 @@ __global__ __launch_bounds__(256) void attn_probs_x3_kernel(const char *__restri
             }
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NQ; ++s) {
             kh[s] = nh[s];
             kl[s] = nl[s];
         }
@@ -1420,7 +1428,21 @@ hipError_t launch_attention_generic(int prec, const float *qkv, void *ctx, float
 }
 
 hipError_t launch_attention(int prec, const void *q, const void *k, const void *vt, void *ctx, float *lse2, int batch,
-                            int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
+                            int n_tokens, int n_pad, int heads, float scale, hipStream_t s, int head_dim) {
+    if (head_dim == 128 && prec == 2) {  // 128-wide heads (model.py:93-103): split-bf16 only, four wavefronts, two stages
+        if (n_pad % 32) return hipErrorInvalidValue;
+        const dim3 g128(((n_tokens + 31) / 32 + 3) / 4, batch * heads), b128(256);
+        if (ctx)
+            attn_fwd_x3_dma_kernel<true, 4, 2, 128, 2><<<g128, b128, 0, s>>>((const char *)q, (const char *)k, (const char *)vt,
+                                                                             (char *)ctx, lse2, n_tokens, n_pad, heads,
+                                                                             scale * LOG2E, 0);
+        else
+            attn_fwd_x3_dma_kernel<false, 4, 2, 128, 2><<<g128, b128, 0, s>>>((const char *)q, (const char *)k, (const char *)vt,
+                                                                              (char *)ctx, lse2, n_tokens, n_pad, heads,
+                                                                              scale * LOG2E, 0);
+        return hipGetLastError();
+    }
+    if (head_dim != 64) return hipErrorInvalidValue;
     if (!prec)
         return launch_attention_bf16((const bf16 *)q, (const bf16 *)k, (const bf16 *)vt, (bf16 *)ctx, lse2, batch,
                                      n_tokens, n_pad, heads, scale, s);
@@ -1493,11 +1515,17 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
 }
 
 hipError_t launch_attention_probs(int prec, const void *q, const void *k, const float *lse2, float *attn, int batch,
-                                  int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
+                                  int n_tokens, int n_pad, int heads, float scale, hipStream_t s, int head_dim) {
     const int qtiles = (n_tokens + 31) / 32;
     const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
+    if (head_dim == 128 && prec == 2) {
+        attn_probs_x3_kernel<128><<<grid, block, 0, s>>>((const char *)q, (const char *)k, lse2, attn, n_tokens, n_pad,
+                                                         scale * LOG2E);
+        return hipGetLastError();
+    }
+    if (head_dim != 64) return hipErrorInvalidValue;
     if (prec == 2)
-        attn_probs_x3_kernel<<<grid, block, 0, s>>>((const char *)q, (const char *)k, lse2, attn, n_tokens, n_pad,
+        attn_probs_x3_kernel<64><<<grid, block, 0, s>>>((const char *)q, (const char *)k, lse2, attn, n_tokens, n_pad,
                                                     scale * LOG2E);
     else if (prec)
         attn_probs_f32_kernel<<<grid, block, 0, s>>>((const float *)q, (const float *)k, lse2, attn, n_tokens, n_pad,
@@ -1510,7 +1538,7 @@ hipError_t launch_attention_probs(int prec, const void *q, const void *k, const 
 
 // ------------------------------------------------------------------------------------------
 // rows[b][h][i][j-1] = softmax_j(q[query_i] . k[j] * scale), j = 1..N-1   (utils.py:232)
-// elements 8c .. 8c+7 of a 64-element head row as fp32
+// elements 8c .. 8c+7 of a head row as fp32
 __device__ __forceinline__ void load8(const bf16 *rowp, int c, float (&o)[8]) {
     const bf16x8 t = *(const bf16x8 *)(rowp + c * 8);
 #pragma unroll
@@ -1531,7 +1559,7 @@ __device__ __forceinline__ void load8(const sp32 *rowp, int c, float (&o)[8]) { 
     for (int e = 0; e < 8; ++e) o[e] = (float)hi[e] + (float)lo[e];
 }
 
-template <class E>
+template <class E, int HD>
 __global__ __launch_bounds__(64) void attn_rows_kernel(const E *__restrict__ Q, const E *__restrict__ Kk,
                                                        const int32_t *__restrict__ query_rows, int n_rows,
                                                        float *__restrict__ rows, int N, int npad, float scale2) {
@@ -1539,10 +1567,10 @@ __global__ __launch_bounds__(64) void attn_rows_kernel(const E *__restrict__ Q, 
     float *sc = (float *)smem;  // N scores
     const int lane = threadIdx.x, bh = blockIdx.y, qi = blockIdx.x;
     const int query = query_rows ? query_rows[qi] : 0;
-    const E *qp = Q + ((int64_t)bh * npad + query) * 64;
-    float qv[64];
+    const E *qp = Q + ((int64_t)bh * npad + query) * HD;
+    float qv[HD];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
+    for (int c = 0; c < HD / 8; ++c) {
         float t[8];
         load8(qp, c, t);
 #pragma unroll
@@ -1550,10 +1578,10 @@ __global__ __launch_bounds__(64) void attn_rows_kernel(const E *__restrict__ Q, 
     }
     float mx = -INFINITY;
     for (int key = lane; key < N; key += 64) {
-        const E *kp = Kk + ((int64_t)bh * npad + key) * 64;
+        const E *kp = Kk + ((int64_t)bh * npad + key) * HD;
         float acc = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < HD / 8; ++c) {
             float t[8];
             load8(kp, c, t);
 #pragma unroll
@@ -1603,18 +1631,25 @@ hipError_t launch_rows_from_probs(const float *attn, const int32_t *query_rows, 
 }
 
 hipError_t launch_attention_rows(int prec, const void *q, const void *k, const int32_t *query_rows, int n_rows,
-                                 float *rows, int batch, int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
+                                 float *rows, int batch, int n_tokens, int n_pad, int heads, float scale, hipStream_t s,
+                                 int head_dim) {
     if (n_rows <= 0) return hipSuccess;
     const dim3 grid(n_rows, batch * heads), block(64);
     const size_t lds = (size_t)n_tokens * sizeof(float);
+    if (head_dim == 128 && prec == 2) {
+        attn_rows_kernel<sp32, 128><<<grid, block, lds, s>>>((const sp32 *)q, (const sp32 *)k, query_rows, n_rows, rows,
+                                                             n_tokens, n_pad, scale * LOG2E);
+        return hipGetLastError();
+    }
+    if (head_dim != 64) return hipErrorInvalidValue;
     if (prec == 2)
-        attn_rows_kernel<sp32><<<grid, block, lds, s>>>((const sp32 *)q, (const sp32 *)k, query_rows, n_rows, rows,
+        attn_rows_kernel<sp32, 64><<<grid, block, lds, s>>>((const sp32 *)q, (const sp32 *)k, query_rows, n_rows, rows,
                                                         n_tokens, n_pad, scale * LOG2E);
     else if (prec)
-        attn_rows_kernel<float><<<grid, block, lds, s>>>((const float *)q, (const float *)k, query_rows, n_rows, rows,
+        attn_rows_kernel<float, 64><<<grid, block, lds, s>>>((const float *)q, (const float *)k, query_rows, n_rows, rows,
                                                          n_tokens, n_pad, scale * LOG2E);
     else
-        attn_rows_kernel<bf16><<<grid, block, lds, s>>>((const bf16 *)q, (const bf16 *)k, query_rows, n_rows, rows,
+        attn_rows_kernel<bf16, 64><<<grid, block, lds, s>>>((const bf16 *)q, (const bf16 *)k, query_rows, n_rows, rows,
                                                         n_tokens, n_pad, scale * LOG2E);
     return hipGetLastError();
 }

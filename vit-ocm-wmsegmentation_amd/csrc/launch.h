@@ -75,14 +75,16 @@ hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, cons
                               float *x, int dim, hipStream_t s, const StatsOut &so = StatsOut());
 
 // ---- kernels_attn.hip
+// head_dim: 64, or 128 in split-bf16 precision (q / k rows and V^T row groups are then 128 channels wide)
 hipError_t launch_attention(int prec, const void *q, const void *k, const void *vt, void *ctx, float *lse2, int batch,
-                            int n_tokens, int n_pad, int heads, float scale, hipStream_t s);
+                            int n_tokens, int n_pad, int heads, float scale, hipStream_t s, int head_dim = 64);
 hipError_t launch_attention_probs(int prec, const void *q, const void *k, const float *lse2, float *attn, int batch,
-                                  int n_tokens, int n_pad, int heads, float scale, hipStream_t s);
+                                  int n_tokens, int n_pad, int heads, float scale, hipStream_t s, int head_dim = 64);
 hipError_t launch_rows_from_probs(const float *attn, const int32_t *query_rows, int n_rows, float *rows, int batch,
                                   int n_tokens, int heads, hipStream_t s);
 hipError_t launch_attention_rows(int prec, const void *q, const void *k, const int32_t *query_rows, int n_rows,
-                                 float *rows, int batch, int n_tokens, int n_pad, int heads, float scale, hipStream_t s);
+                                 float *rows, int batch, int n_tokens, int n_pad, int heads, float scale, hipStream_t s,
+                                 int head_dim = 64);
 hipError_t launch_attention_map(const float *attn, float *maps, int b, int heads, int n_tokens, int query, int hf,
                                 int wf, int p, hipStream_t s);
 
