@@ -347,6 +347,7 @@ struct Workspace {  // E = bf16 (OCM_PREC_BF16) or float (OCM_PREC_FP32)
     void *hid;    // [T][M] E GELU(fc1)
     float *lse;   // [B*H][N]
     float *qkv32; // [3][B][H][N][hd] fp32: the qkv tensor of heads that are not 64 wide (then q / k / vt are unused)
+    float *part;  // [OCM_SPLITK][T][D] fp32 partial sums of mlp.fc2 when it runs as split-K (T <= OCM_SPLITK_MAX_ROWS), else null
     float *stats; // [2][T][D/64][2] row sums (sum x, sum x^2 per 64-column slot) of the residual stream at the LayerNorm site being
                   // produced / consumed (folded LayerNorm: even sites in half 0, odd sites in half 1)
     size_t bytes;
@@ -366,6 +367,7 @@ static Workspace carve(const ocm_vit *h, int batch, int n, char *base) {
     w.xn = take(T * h->D * e);
     w.lse = (float *)take(BH * n * 4);
     w.stats = h->can_fold() ? (float *)take(2 * T * (size_t)(h->D / 64) * 8) : nullptr;
+    w.part = (h->prec == 2 && T <= (size_t)OCM_SPLITK_MAX_ROWS) ? (float *)take((size_t)OCM_SPLITK * T * h->D * 4) : nullptr;
     // The attention operands (q, k, V^T or the fp32 qkv tensor, then the context) are dead once attn.proj has run, and the
     // hidden activations only live from mlp.fc1 to mlp.fc2: the two groups share one region. ViT-S/16 at B = 64 in
     // split-bf16: 123 MB instead of 195 MB, which with the 85 MB of weights keeps a forward's working set inside the
@@ -472,7 +474,10 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
         if (xn_out) *xn_out = true;
     } else {
         PROF(OCM_K_FC2, s);
-        HIP_TRY(launch_linear(pc, w.hid, h->ptr<char>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s));
+        StatsOut so;
+        if (fuse_opt == 0) so.part = w.part;  // few rows: split-K (launch.h); an explicit OCM_OPT_FUSE_LN setting keeps the plain
+                                              // kernel, whose accumulation order the fused GEMM + LayerNorm kernel shares
+        HIP_TRY(launch_linear(pc, w.hid, h->ptr<char>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s, LnFold(), so));
     }
     return OCM_OK;
 }
@@ -523,6 +528,7 @@ static int run_block_folded(const ocm_vit *h, int i, const Workspace &w, float *
     StatsOut so_mid, so_out;
     so_mid.xs = w.xn, so_mid.stats = st_mid;
     so_out.xs = w.xn, so_out.stats = st_out;
+    so_out.part = w.part;  // few rows: mlp.fc2 as split-K (launch.h)
     { PROF(OCM_K_PROJ, s); HIP_TRY(launch_linear(pc, w.ctx, h->ptr<char>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s, LnFold(), so_mid)); }
     { PROF(OCM_K_FC1, s); HIP_TRY(launch_linear(pc, w.xn, h->ptr<char>(bp.fc1_wf), nullptr, nullptr, w.hid, T, h->M, D, OCM_EPI_BIAS_GELU_BF16, s, ln2)); }
     { PROF(OCM_K_FC2, s); HIP_TRY(launch_linear(pc, w.hid, h->ptr<char>(bp.fc2_w), h->ptr<float>(bp.fc2_b), x, x, T, D, h->M, OCM_EPI_BIAS_RESID_F32, s, LnFold(), so_out)); }

@@ -447,6 +447,40 @@ static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, 
     return launch_linear_epi<MODE, E>(a, w, epi, M, N, K, s);
 }
 
+// Split-K form of the LDS-DMA nn.Linear kernel for few rows and a long contraction (launch.h: StatsOut::part): blockIdx.y is
+// the K slice, the accumulator tile goes to part[slice] as plain fp32 (no bias); launch_splitk_finish adds the slices.
+template <class Cfg, class E, int KSTEPS, int NSTAGE>
+__global__ __launch_bounds__(Cfg::NT) void gemm_dma_splitk_kernel(const E *__restrict__ A, int64_t lda,
+                                                                  const E *__restrict__ W, int64_t ldw, int M, int N,
+                                                                  int Kslice, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_n = (N + Cfg::BN - 1) / Cfg::BN;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n, slice = blockIdx.y;
+    const int m0 = tm * Cfg::BM, n0 = tn * Cfg::BN;
+    EpiLinear<0, E> epi{nullptr, nullptr, part + (size_t)slice * M * N, M, N, N};
+    f32x16 acc[Cfg::TM][Cfg::TN];
+    const auto pre = epi_prefetch<Cfg>(epi, m0, n0, M, N);
+    gemm_mainloop_dma<Cfg, E, false, KSTEPS, NSTAGE>(A + (size_t)slice * Kslice, lda, W + (size_t)slice * Kslice, ldw, m0, n0, M,
+                                                     N, Kslice, smem, acc, (const float *)nullptr);
+    run_epilogue<Cfg, false, EpiLinear<0, E>, NSTAGE * (Cfg::BM + Cfg::BN) * 128, decltype(pre)>(acc, smem, epi, m0, n0, true,
+                                                                                                  &pre);
+}
+
+template <class E>
+static hipError_t launch_linear_splitk(const E *a, const E *w, const float *bias, const float *resid, float *x, int M, int N,
+                                       int K, hipStream_t s, const StatsOut &so) {
+    typedef Cfg64x64 Cfg;
+    constexpr int NSTAGE = 4, KS = 12;  // K / OCM_SPLITK = 384 elements = 12 steps (ViT-S mlp.fc2); other depths: no split
+    constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
+    auto kern = gemm_dma_splitk_kernel<Cfg, E, KS, NSTAGE>;
+    static unsigned long long optin = 0;
+    if (hipError_t e = ensure_lds_optin((const void *)kern, LDS, optin); e != hipSuccess) return e;
+    const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * (N / Cfg::BN);
+    kern<<<dim3(tiles, OCM_SPLITK), dim3(Cfg::NT), LDS, s>>>(a, K, w, K, M, N, K / OCM_SPLITK, so.part);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    return launch_splitk_finish(so.part, OCM_SPLITK, bias, resid, x, so.xs, so.stats, M, N, s);
+}
+
 // epilogue 4 (internal): x = resid + acc + bias in place, plus split pairs and row sums of x (StatsOut)
 template <class E>
 hipError_t launch_linear_e(const E *a, const E *w, const float *bias, const float *resid, void *out, int M, int N,
@@ -454,6 +488,10 @@ hipError_t launch_linear_e(const E *a, const E *w, const float *bias, const floa
     switch (epilogue) {
         case 0: return launch_linear_mode<0, E>(a, w, bias, resid, out, M, N, K, s);
         case 1:
+            if constexpr (Elem<E>::MODE == 2)
+                if (so.part && M <= OCM_SPLITK_MAX_ROWS && N % 64 == 0 && K == OCM_SPLITK * 12 * Elem<E>::KROW && resid &&
+                    (!so.stats || so.xs))
+                    return launch_linear_splitk<E>(a, w, bias, resid, (float *)out, M, N, K, s, so);
             if (so.stats) {
                 if (N % 64) return hipErrorInvalidValue;
                 EpiResidStats<E> epi{bias, resid, (float *)out, so.xs, so.stats, M, N};

@@ -341,6 +341,55 @@ hipError_t launch_cls_rows_stats(const float *cls, const float *pos, float *x, v
     return hipGetLastError();
 }
 
+// Split-K finish (launch.h: StatsOut::part): one wavefront per output row adds the partial sums of the K slices in slice
+// order to bias + residual, writes x (fp32, may alias resid) and, for a folded LayerNorm downstream, the split pairs and
+// the row sums of x in the slot layout of EpiResidStats (slot 0 = sums of the whole row, the other slots zero).
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float *__restrict__ part, int slices,
+                                                            const float *__restrict__ bias, const float *resid,
+                                                            float *x, char *__restrict__ xs, float *__restrict__ stats,
+                                                            int M, int N) {
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const size_t row = (size_t)m * N, slice = (size_t)M * N;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < N; c += 256) {
+        f32x4 v = *(const f32x4 *)(resid + row + c);
+        if (bias) v += *(const f32x4 *)(bias + c);
+        for (int k = 0; k < slices; ++k) v += *(const f32x4 *)(part + k * slice + row + c);
+        *(f32x4 *)(x + row + c) = v;
+        if (xs) {
+            bf16x4 hi, lo;
+            split4(v, hi, lo);
+            char *g = xs + row * 4 + sp_off(c);
+            *(bf16x4 *)g = hi;
+            *(bf16x4 *)(g + 64) = lo;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s1 += v[e];
+            s2 = fmaf(v[e], v[e], s2);
+        }
+    }
+    if (!stats) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
+    }
+    const int nslot = N >> 6;
+    if (lane < nslot) {
+        stats[((size_t)m * nslot + lane) * 2] = lane ? 0.f : s1;
+        stats[((size_t)m * nslot + lane) * 2 + 1] = lane ? 0.f : s2;
+    }
+}
+
+hipError_t launch_splitk_finish(const float *part, int slices, const float *bias, const float *resid, float *x, void *xs,
+                                float *stats, int M, int N, hipStream_t s) {
+    if (N % 4 || (stats && (N % 64 || N / 64 > 64)) || slices <= 0 || M <= 0) return hipErrorInvalidValue;
+    splitk_finish_kernel<<<dim3((M + 3) / 4), dim3(256), 0, s>>>(part, slices, bias, resid, x, (char *)xs, stats, M, N);
+    return hipGetLastError();
+}
+
 // W (N, K) fp32, gamma / beta (K), bias (N) -> W' = W * gamma as split pairs, c (N), d (N). One wavefront per output row;
 // the two row sums in float64 (they multiply O(1) row statistics in every epilogue).
 __global__ __launch_bounds__(64) void fold_ln_kernel(const float *__restrict__ W, const float *__restrict__ gamma,

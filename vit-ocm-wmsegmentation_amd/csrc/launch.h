@@ -35,7 +35,15 @@ struct LnFold {
 struct StatsOut {
     void *xs = nullptr;      // [rows][N] split pairs of x, or null
     float *stats = nullptr;  // [rows][N / 64][2]
+    // Few rows and a long contraction (mlp.fc2 of a one-tile-per-call forward: M = 197, K = 1536 on 24 workgroups): the K range
+    // is cut into OCM_SPLITK slices, one workgroup per (tile, slice) writes fp32 partial sums here ([slices][M][N]) and a row
+    // kernel adds them in slice order with bias and residual (and produces xs / stats). Null: never split.
+    float *part = nullptr;
 };
+constexpr int OCM_SPLITK = 4, OCM_SPLITK_MAX_ROWS = 512;
+// x = resid + bias + sum over slices of part[slice] (fixed order); optionally split pairs and row sums of x
+hipError_t launch_splitk_finish(const float *part, int slices, const float *bias, const float *resid, float *x, void *xs,
+                                float *stats, int M, int N, hipStream_t s);
 hipError_t launch_cls_rows_stats(const float *cls, const float *pos, float *x, void *xs, float *stats, int batch,
                                  int n_tokens, int dim, hipStream_t s);
 hipError_t launch_fold_ln(const float *W, const float *gamma, const float *beta, const float *bias, void *Wf, float *cvec,

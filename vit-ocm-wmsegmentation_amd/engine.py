@@ -172,8 +172,10 @@ class Engine:
                 out["tokens"] = torch.empty((B, n, D), **kw)
                 io.out_tokens = out["tokens"].data_ptr()
             if flags & OCM_OUT_ROWS:
-                if query_rows is None:
-                    query_rows = torch.zeros(1, dtype=torch.int32, device=self.device)
+                if query_rows is None:  # the CLS row: one resident index tensor per engine, not a fill kernel per forward
+                    query_rows = self.__dict__.get("_cls_row")
+                    if query_rows is None:
+                        query_rows = self.__dict__["_cls_row"] = torch.zeros(1, dtype=torch.int32, device=self.device)
                 _require_hip(query_rows, "query_rows")
                 query_rows = query_rows.to(torch.int32).contiguous()
                 out["rows"] = torch.empty((B, H, query_rows.numel(), n - 1), **kw)
