@@ -347,6 +347,8 @@ struct Workspace {  // E = bf16 (OCM_PREC_BF16) or float (OCM_PREC_FP32)
     void *hid;    // [T][M] E GELU(fc1)
     float *lse;   // [B*H][N]
     float *qkv32; // [3][B][H][N][hd] fp32: the qkv tensor of heads that are not 64 wide (then q / k / vt are unused)
+    float *kpart; // key-slice partial results of the attention at long sequences and small batch (launch.h), or null
+    size_t kpart_bytes;
     float *part;  // [OCM_SPLITK][T][D] fp32 partial sums of mlp.fc2 when it runs as split-K (T <= OCM_SPLITK_MAX_ROWS), else null
     float *stats; // [2][T][D/64][2] row sums (sum x, sum x^2 per 64-column slot) of the residual stream at the LayerNorm site being
                   // produced / consumed (folded LayerNorm: even sites in half 0, odd sites in half 1)
@@ -368,6 +370,8 @@ static Workspace carve(const ocm_vit *h, int batch, int n, char *base) {
     w.lse = (float *)take(BH * n * 4);
     w.stats = h->can_fold() ? (float *)take(2 * T * (size_t)(h->D / 64) * 8) : nullptr;
     w.part = (h->prec == 2 && T <= (size_t)OCM_SPLITK_MAX_ROWS) ? (float *)take((size_t)OCM_SPLITK * T * h->D * 4) : nullptr;
+    w.kpart_bytes = attention_ksplit_bytes(h->prec, batch, n, h->H, h->hd);
+    w.kpart = w.kpart_bytes ? (float *)take(w.kpart_bytes) : nullptr;
     // The attention operands (q, k, V^T or the fp32 qkv tensor, then the context) are dead once attn.proj has run, and the
     // hidden activations only live from mlp.fc1 to mlp.fc2: the two groups share one region. ViT-S/16 at B = 64 in
     // split-bf16: 123 MB instead of 195 MB, which with the 85 MB of weights keeps a forward's working set inside the
@@ -452,7 +456,7 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
         }
         return OCM_OK;
     }
-    { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s, h->hd)); }
+    { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s, h->hd, w.kpart, w.kpart_bytes)); }
     if (out_attn) {
         { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s, h->hd)); }
         if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
@@ -519,7 +523,7 @@ static int run_block_folded(const ocm_vit *h, int i, const Workspace &w, float *
             }
             return OCM_OK;
         }
-        { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s, h->hd)); }
+        { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, w.ctx, out_attn ? w.lse : nullptr, batch, n, np, H, scale, s, h->hd, w.kpart, w.kpart_bytes)); }
         if (out_attn) {
             { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s, h->hd)); }
             if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }

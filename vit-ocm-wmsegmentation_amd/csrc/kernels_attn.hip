@@ -859,12 +859,15 @@ extern "C" int ocm_debug_stamps_attn(unsigned long long *host, int n) {
 // are zeroed in LDS after the tile has landed (the qkv epilogue never writes them; 0 * garbage must not be NaN).
 // HD = head width: 64 (the DINO ViTs), or 128 (the reference's SimMIM encoder, model.py:93-103) on a two-stage ring of
 // 32 KiB stages (K: four [32 keys][128 B] images, V^T: [128 d][128 B]) with twice the Q fragments and context accumulators.
-template <bool WANT_O, int NW, int WPS, int HD = 64, int NSTAGE = 3>
+// KSPLIT: long sequences at small batch (one 384^2 window of ViT-S/8 per call: 60 workgroups walking 73 key tiles each).
+// blockIdx.z owns a contiguous range of key tiles and leaves its UNNORMALISED context rows, running maximum and sum in `part`
+// ([slice][B*H][N][HD + 4] fp32: context, maximum, sum, pad); attn_merge_x3_kernel combines the slices (the flash-decoding reduction).
+template <bool WANT_O, int NW, int WPS, int HD = 64, int NSTAGE = 3, bool KSPLIT = false>
 __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const char *__restrict__ Q,
                                                                        const char *__restrict__ Kk,
                                                                        const char *__restrict__ Vt, char *__restrict__ ctx,
                                                                        float *__restrict__ lse2, int N, int npad, int H,
-                                                                       float scale2, int wt) {
+                                                                       float scale2, int wt, float *__restrict__ part = nullptr) {
     constexpr int KB = HD * 128, STAGE = 2 * KB, KP = HD / 8 / NW, VP = WANT_O ? HD / 8 / NW : 0, LPS = KP + VP;  // KB: K bytes of a 32-key tile
     constexpr int NQ = HD / 16, ND = HD / 32;  // k slices of the score product, 32-channel blocks of the context
     static_assert((NW == 4 || NW == 8) && (HD == 64 || HD == 128) && (NSTAGE == 2 || NSTAGE == 3), "HD / 8 pieces of 1 KiB per operand and tile");
@@ -881,7 +884,13 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
     const char *Qb = Q + (int64_t)bh * npad * (HD * 4);
     const char *Kb = Kk + (int64_t)bh * npad * (HD * 4);
     const char *Vb = Vt + (int64_t)bh * HD * npad * 4;
-    const int ntiles = (N + 31) >> 5;
+    const int ntiles = (N + 31) >> 5;  // key tiles of the sequence; this workgroup walks nt of them from tile tb
+    int tb = 0, nt = ntiles;
+    if (KSPLIT) {
+        const int per = (ntiles + (int)gridDim.z - 1) / (int)gridDim.z;
+        tb = (int)blockIdx.z * per;
+        nt = min(per, ntiles - tb);  // >= 1: the launcher sizes gridDim.z so
+    }
 
     // Q^T as the B operand: issued first, so the counted waits below cover it too (vmcnt retires in order)
     bf16x8 qh[NQ], ql[NQ];
@@ -928,8 +937,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
 #define OCM_ATTN_DMA(t, st) (void)0
 #endif
 
-    OCM_ATTN_DMA(0, 0);
-    if (NSTAGE == 3 && ntiles > 1) OCM_ATTN_DMA(1, 1);
+    OCM_ATTN_DMA(tb, 0);
+    if (NSTAGE == 3 && nt > 1) OCM_ATTN_DMA(tb + 1, 1);
     // Q and the first two tiles have landed before the loop (builtin, not asm: hipcc's own wait-count bookkeeping must
     // see that the Q registers are complete, or it re-waits for them inside the loop with a count that also covers the
     // tile in flight). 0x0F70 = vmcnt(0), expcnt / lgkmcnt untouched.
@@ -946,9 +955,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
     const int first_pad = N - (ntiles - 1) * 32;  // valid keys of the last tile (1..32)
     int sc = 0, si = NSTAGE - 1;                  // stage computed next / filled next
 
-    for (int kt = 0; kt < ntiles; ++kt) {
+    for (int kt = 0; kt < nt; ++kt) {
+        const bool last_of_seq = tb + kt + 1 == ntiles;  // the tile that holds the padding keys
         // own DMAs of tile kt have landed once at most the younger tile kt+1 is pending
-        if (NSTAGE == 3 && kt + 1 < ntiles)
+        if (NSTAGE == 3 && kt + 1 < nt)
             OCM_VMCNT_ATTN(LPS);
         else
             OCM_VMCNT_ATTN(0);
@@ -959,10 +969,10 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
         asm volatile("" ::: "memory");
         ASTAMP(2 + kt);  // barrier of tile kt passed
 #if !defined(OCM_ABL) || OCM_ABL != 5  // ablation 5: no staging after the prologue
-        if (kt + NSTAGE - 1 < ntiles) OCM_ATTN_DMA(kt + NSTAGE - 1, si);  // into the stage of tile kt-1: everybody is past it
+        if (kt + NSTAGE - 1 < nt) OCM_ATTN_DMA(tb + kt + NSTAGE - 1, si);  // into the stage of tile kt-1: everybody is past it
 #endif
         char *Kt = smem + sc * STAGE, *Vtile = Kt + KB;
-        if (WANT_O && kt + 1 == ntiles && first_pad < 32) {  // zero the V^T columns of the padding keys (wave-uniform)
+        if (WANT_O && last_of_seq && first_pad < 32) {  // zero the V^T columns of the padding keys (wave-uniform)
             if (tid < 256) {
                 const int kc = tid & 3;
                 if (kc * 8 + 8 > first_pad) {
@@ -996,7 +1006,7 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
                 const bf16x8 kl = *(const bf16x8 *)(kp + lds_off(pr, 4 + (s & 1) * 2 + h));
                 S = mfma32x3(kh, kl, qh[s], ql[s], S);
             }
-            if (kt + 1 == ntiles && first_pad < 32) {  // padding keys -> -inf (wave-uniform branch)
+            if (last_of_seq && first_pad < 32) {  // padding keys -> -inf (wave-uniform branch)
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     if (key_of_reg(e, h) >= first_pad) S[e] = -INFINITY;
@@ -1052,6 +1062,22 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
     if (!active) return;
     const float lt = l + __shfl_xor(l, 32, 64);
     const int qrow = q0 + r;
+    if (KSPLIT) {
+        if (qrow < N) {
+            float *dst = part + (((int64_t)blockIdx.z * gridDim.y + bh) * N + qrow) * (HD + 4);
+            if (h == 0) *(f32x2 *)(dst + HD) = f32x2{m, lt};
+#pragma unroll
+            for (int db = 0; db < ND; ++db)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = O[db][4 * g + e];
+                    *(f32x4 *)(dst + 32 * db + 8 * g + 4 * h) = o;
+                }
+        }
+        return;
+    }
     if (qrow < N) {
         if (lse2 && h == 0) lse2[(int64_t)bh * N + qrow] = m + __log2f(lt);
         if (WANT_O) {
@@ -1083,6 +1109,37 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
     ASTAMP_RT(13);
 }
 
+
+// Combines the key slices of attn_fwd_x3_dma_kernel<..., KSPLIT>: 16 lanes per query row (four channels each),
+//   m = max_s m_s,  L = sum_s l_s 2^(m_s - m),  ctx = sum_s O_s 2^(m_s - m) / L  (as split pairs),  lse2 = m + log2 L.
+template <int HD>
+__global__ __launch_bounds__(256) void attn_merge_x3_kernel(const float *__restrict__ part, int nslice, char *__restrict__ ctx,
+                                                            float *__restrict__ lse2, int BH, int N, int H) {
+    constexpr int LPR = HD / 4;  // lanes per row
+    const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;  // bh * N + query
+    if (row >= (int64_t)BH * N) return;
+    const int c = (threadIdx.x % LPR) * 4;
+    const int64_t stride = (int64_t)BH * N * (HD + 4);
+    const float *p = part + row * (HD + 4);
+    float m = -INFINITY;
+    for (int s = 0; s < nslice; ++s) m = fmaxf(m, p[s * stride + HD]);
+    float L = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nslice; ++s) {
+        const f32x2 ml = *(const f32x2 *)(p + s * stride + HD);
+        const float wgt = fast_exp2(ml[0] - m);
+        L = fmaf(ml[1], wgt, L);
+        o += *(const f32x4 *)(p + s * stride + c) * wgt;
+    }
+    const float inv = 1.0f / L;
+    const int bh = (int)(row / N), q = (int)(row - (int64_t)bh * N), b = bh / H, head = bh - b * H;
+    bf16x4 hi, lo;
+    split4(o * inv, hi, lo);
+    char *dst = ctx + ((int64_t)b * N + q) * (H * HD) * 4 + head * (HD * 4) + sp_off(c);
+    *(bf16x4 *)dst = hi;
+    *(bf16x4 *)(dst + 64) = lo;
+    if (lse2 && c == 0) lse2[row] = m + __log2f(L);
+}
 
 // Whole-sequence variant of attn_fwd_x3_kernel for N <= 256 (ViT-S/16 and ViT-B/16 at 224^2: N = 197): one workgroup
 // of 8 waves per (batch, head). ALL K and V^T tiles of the head (hi + lo halves: up to 128 KiB) are brought into LDS
@@ -1427,8 +1484,16 @@ hipError_t launch_attention_generic(int prec, const float *qkv, void *ctx, float
     return hipGetLastError();
 }
 
+size_t attention_ksplit_bytes(int prec, int batch, int n_tokens, int heads, int head_dim) {
+    if (prec != 2 || head_dim != 64 || n_tokens <= 1024) return 0;
+    const int wgs = (((n_tokens + 31) / 32 + 7) / 8) * batch * heads;
+    if (wgs > 128) return 0;
+    return (size_t)4 * batch * heads * n_tokens * (64 + 4) * sizeof(float);
+}
+
 hipError_t launch_attention(int prec, const void *q, const void *k, const void *vt, void *ctx, float *lse2, int batch,
-                            int n_tokens, int n_pad, int heads, float scale, hipStream_t s, int head_dim) {
+                            int n_tokens, int n_pad, int heads, float scale, hipStream_t s, int head_dim, float *ksplit_ws,
+                            size_t ksplit_bytes) {
     if (head_dim == 128 && prec == 2) {  // 128-wide heads (model.py:93-103): split-bf16 only, four wavefronts, two stages
         if (n_pad % 32) return hipErrorInvalidValue;
         const dim3 g128(((n_tokens + 31) / 32 + 3) / 4, batch * heads), b128(256);
@@ -1480,6 +1545,26 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
         // long sequences: 8 waves per workgroup share each K / V^T tile (half the L2 -> LDS traffic per query)
         const bool wide = (n_tokens > 1024 && OCM_KNOB(7) != 1) || OCM_KNOB(7) == 2;
         const dim3 grid8((qtiles + 7) / 8, batch * heads), block8(512);
+        // Long sequence, few workgroups (one ViT-S/8 window per call: 60 of them, 73 key tiles each): cut the key range into
+        // up to four slices per workgroup and merge (attn_merge_x3_kernel)
+        // (not for a block whose probabilities are returned: their log-sum-exp then comes from the one kernel that also serves
+        // get_last_selfattention's statistics-only pass, so both entry points return the same bits)
+        if (wide && ctx && !lse2 && ksplit_ws && OCM_KNOB(7) == 0) {
+            const int wgs = (int)(grid8.x * grid8.y), ktiles = (n_tokens + 31) / 32;
+            int want = wgs <= 64 ? 4 : wgs <= 96 ? 3 : wgs <= 128 ? 2 : 1;
+            const int per = (ktiles + want - 1) / want, nslice = (ktiles + per - 1) / per;  // every slice owns >= 1 tile
+            const size_t need = (size_t)nslice * batch * heads * n_tokens * (64 + 4) * sizeof(float);
+            if (nslice > 1 && need <= ksplit_bytes) {
+                attn_fwd_x3_dma_kernel<true, 8, 2, 64, 3, true><<<dim3(grid8.x, grid8.y, nslice), block8, 0, s>>>(
+                    (const char *)q, (const char *)k, (const char *)vt, (char *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E, 0,
+                    ksplit_ws);
+                if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+                const int64_t rows = (int64_t)batch * heads * n_tokens;
+                attn_merge_x3_kernel<64><<<dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s>>>(
+                    ksplit_ws, nslice, (char *)ctx, lse2, batch * heads, n_tokens, heads);
+                return hipGetLastError();
+            }
+        }
 #define OCM_X3_ATTN(WO, NW_, G, B_)                                                                                      \
     attn_fwd_x3_kernel<WO, NW_><<<G, B_, 0, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx, lse2, \
                                                  n_tokens, n_pad, heads, scale * LOG2E, (ocm_wt_mask() >> 4) & 1)

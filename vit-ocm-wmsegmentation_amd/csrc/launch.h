@@ -85,7 +85,10 @@ hipError_t launch_patch_embed(int prec, const PatchArgs &pa, const void *w, cons
 // ---- kernels_attn.hip
 // head_dim: 64, or 128 in split-bf16 precision (q / k rows and V^T row groups are then 128 channels wide)
 hipError_t launch_attention(int prec, const void *q, const void *k, const void *vt, void *ctx, float *lse2, int batch,
-                            int n_tokens, int n_pad, int heads, float scale, hipStream_t s, int head_dim = 64);
+                            int n_tokens, int n_pad, int heads, float scale, hipStream_t s, int head_dim = 64,
+                            float *ksplit_ws = nullptr, size_t ksplit_bytes = 0);
+// bytes of key-slice workspace launch_attention can use at this size (0: it never splits the key range)
+size_t attention_ksplit_bytes(int prec, int batch, int n_tokens, int heads, int head_dim);
 hipError_t launch_attention_probs(int prec, const void *q, const void *k, const float *lse2, float *attn, int batch,
                                   int n_tokens, int n_pad, int heads, float scale, hipStream_t s, int head_dim = 64);
 hipError_t launch_rows_from_probs(const float *attn, const int32_t *query_rows, int n_rows, float *rows, int batch,
