@@ -21,6 +21,9 @@ int ocm_wt_mask();  // kernels_gemm.hip
 #ifndef OCM_SMALLM_STAGES
 #define OCM_SMALLM_STAGES 4
 #endif
+// ... and up to how many rows they are chosen (tried 4096 for one ViT-S/8 window of 384^2 per call, 2305 rows on 111 .. 444
+// workgroups: attn.qkv 18.8 -> 21.8 us, mlp.fc1 16.2 -> 17.5, attn.proj 10.9 -> 9.8 — the register-staged loop stays there)
+constexpr int OCM_SMALLM_ROWS = 1024;
 typedef GemmCfg<128, 128, 2, 2> Cfg128x128;
 // the qkv projection runs the same tile with 8 waves (32x64 MFMA sub-tiles per wave): two waves per SIMD inside
 // one workgroup overlap its heavier scatter epilogue with the other waves' MFMAs (29.0 -> 25.8 us at ViT-S, B=64)
@@ -394,7 +397,7 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
         // Few rows (the reference's one-tile-per-call loops, M = 197 .. 785): everything is L2-resident and a launch is a
         // handful of workgroups, so the LDS-DMA loop's shorter prologue shows (stand-alone, M = 197: fc1 9.4 -> 7.9 us,
         // fc2 23.1 -> 16.7 us on 64x64 tiles with a 4-deep ring, proj 8.3 -> 7.6 us)
-        if (M <= 1024 && OCM_KNOB(0) == 0) {
+        if (M <= OCM_SMALLM_ROWS && OCM_KNOB(0) == 0) {
             if (K >= 1024 && N % 64 == 0) return launch_gemm_dma<Cfg64x64, E, 4>(a, K, w, K, M, N, K, epi, s);
             if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, OCM_SMALLM_STAGES>(a, K, w, K, M, N, K, epi, s);
         }
@@ -915,7 +918,7 @@ hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E
 #endif
             if (OCM_KNOB(3) == 0) {
                 // few rows (one tile per call): the DMA loop's shorter prologue shows (B = 1 forward 1.03 -> 1.01 ms)
-                if (M <= 1024) return launch_qkv_dma<Cfg64x128, E, OCM_SMALLM_STAGES>(a, w, M, D, eqk, ev, s);
+                if (M <= OCM_SMALLM_ROWS) return launch_qkv_dma<Cfg64x128, E, OCM_SMALLM_STAGES>(a, w, M, D, eqk, ev, s);
                 // ViT-B sizes: 256 x 256 tiles halve the bytes through L2 (384^2 B = 128: 755 -> 715 us per launch)
                 if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_dma<Cfg256x256, E, 2>(a, w, M, D, eqk, ev, s);
                 // the 8-wave 128 x 128 tile on the LDS-DMA loop (ViT-S/16 B = 64: 46.6 -> 41.8 us per launch, +2 % end
