@@ -354,6 +354,7 @@ def test_hip_graph_replay_matches_plain_launches(dev):
     bit-identical to plain launches, a pointer / shape change re-captures, and weights can change under the graph."""
     case = CASES["tiny_p8"]
     model = build_module(case, dev)
+    model.auto_graph = False  # the engine-level cache on its own (the module's automatic replay has its own test below)
     eng = model._engine(dev)
     x1 = case_inputs(case)[0][:1].to(dev)
     x2 = (x1 * 0.5 + 0.1).contiguous()
@@ -382,6 +383,52 @@ def test_hip_graph_replay_matches_plain_launches(dev):
     eng2.hip_graph = False
     assert torch.equal(model.get_last_selfattention(x1), changed)
     assert not torch.equal(changed, want1)
+
+
+def test_one_tile_calls_replay_a_graph_automatically(dev):
+    """Plain one-tile calls (the reference's loops, eval.py:126-171) are replayed as a HIP graph by the module itself:
+    same bits as the launch-by-launch path, new inputs followed, a parameter update or precision change re-captured,
+    larger batches left alone."""
+    case = CASES["vits16_peaked"]
+    model = build_module(case, dev)
+    x = case_inputs(case)[0][:1].to(dev)
+    x2 = torch.flip(x, dims=(-1,)).contiguous()
+    model.auto_graph = False
+    want = [model.get_last_selfattention(x), model.get_last_selfattention(x2)]
+    feat_want = model.get_intermediate_feat(x, 2)
+    rows_want = model.get_last_attention_rows(x, torch.tensor([0, 5], dtype=torch.int32, device=dev))
+    model.auto_graph = True
+    for _ in range(3):  # capture, then replays
+        assert torch.equal(model.get_last_selfattention(x), want[0])
+        assert torch.equal(model.get_last_selfattention(x2), want[1])
+    assert len(model._auto_graphs) == 1
+    got = model.get_intermediate_feat(x, 2)
+    for a, b in zip(feat_want, got):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    qr = torch.tensor([0, 5], dtype=torch.int32, device=dev)
+    for _ in range(2):
+        assert torch.equal(model.get_last_attention_rows(x, qr), rows_want)
+    # returned tensors are copies: a later call does not overwrite them
+    a = model.get_last_selfattention(x)
+    b = model.get_last_selfattention(x2)
+    assert torch.equal(a, want[0]) and torch.equal(b, want[1]) and a.data_ptr() != b.data_ptr()
+    # in-place parameter update: the next call sees it
+    with torch.no_grad():
+        model.blocks[0].attn.qkv.weight.mul_(1.5)
+    changed = model.get_last_selfattention(x)
+    model.auto_graph = False
+    assert torch.equal(changed, model.get_last_selfattention(x)) and not torch.equal(changed, want[0])
+    model.auto_graph = True
+    # another precision: another engine, another capture
+    a32 = model.set_precision("fp32").get_last_selfattention(x)
+    model.auto_graph = False
+    assert torch.equal(a32, model.get_last_selfattention(x))
+    model.auto_graph = True
+    # batches beyond AUTO_GRAPH_TOKENS rows run launch by launch
+    n_before = len(model._auto_graphs)
+    model.get_last_selfattention(torch.cat([x] * 6))
+    assert len(model._auto_graphs) == n_before
 
 
 @pytest.mark.parametrize("method,kwargs", [("get_last_selfattention", {}), ("get_intermediate_feat", {"n": 2}),

@@ -769,13 +769,71 @@ struct EpiVt {
     template <class Cfg>
     __device__ __forceinline__ void run(const float *C, int m0, int n0, const f32x2 *rowtab, const f32x2 *coltab) const {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
+        const int rem0 = n0 - 2 * D;
+        // Split pairs, one tile per call (and any tile that lies inside one image at an aligned offset): a lane owns EIGHT
+        // consecutive tokens of one feature row — two 16-byte stores (hi, lo) instead of sixteen 2-byte ones; the ragged last
+        // piece of the sequence goes element by element.
+        if constexpr (Elem<E>::MODE == 2 && NT >= BM / 8) {
+            // chosen per tile (workgroup-uniform): all its rows in one image, starting at a multiple of eight tokens. Other
+            // tiles keep the token-per-lane form below, whose element stores are contiguous across the wavefront.
+            const int b0 = m0 / ntok, t0 = m0 - b0 * ntok;
+            if (vt && (t0 & 7) == 0 && t0 + min(BM, M - m0) <= ntok) {
+                constexpr int GPR = BM / 8;  // token groups per feature row
+                for (int q = threadIdx.x; q < BN * GPR; q += NT) {
+                    const int row = q / GPR, g = q - row * GPR, m = m0 + g * 8;
+                    if (m >= M) continue;
+                    const int b = m / ntok, t = m - b * ntok;
+                    const int rem = rem0 + row;
+                    const int head = hd == 64 ? rem >> 6 : rem / hd, d = rem - head * hd;
+                    f32x4 v0 = *(const f32x4 *)(C + row * BM + g * 8), v1 = *(const f32x4 *)(C + row * BM + g * 8 + 4);
+                    if (ln.stats) {
+                        const f32x2 cd = coltab[row];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const f32x2 r0 = rowtab[g * 8 + e], r1 = rowtab[g * 8 + 4 + e];
+                            v0[e] = fmaf(r0[1], fmaf(-r0[0], cd[0], v0[e]), cd[1]);
+                            v1[e] = fmaf(r1[1], fmaf(-r1[0], cd[0], v1[e]), cd[1]);
+                        }
+                    }
+                    char *rowp = (char *)vt + ((int64_t)(b * H + head) * hd + d) * npad * 4;
+                    if ((t & 7) == 0 && t + 8 <= ntok && m + 8 <= M) {
+                        bf16x8 hi, lo;
+                        split8(v0, v1, hi, lo);
+                        *(bf16x8 *)(rowp + sp_off(t)) = hi;
+                        *(bf16x8 *)(rowp + sp_off(t) + 64) = lo;
+                        if (qkv32) {
+                            float *o = qkv32 + ((((int64_t)2 * B + b) * H + head) * ntok + t) * hd + d;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                o[(int64_t)e * hd] = v0[e];
+                                o[(int64_t)(4 + e) * hd] = v1[e];
+                            }
+                        }
+                    } else {
+                        int bb = b, tt = t;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (m + e < M) {
+                                const float v = e < 4 ? v0[e & 3] : v1[e & 3];
+                                store_act1((E *)nullptr, (char *)vt + ((int64_t)(bb * H + head) * hd + d) * npad * 4, tt, v);
+                                if (qkv32) qkv32[((((int64_t)2 * B + bb) * H + head) * ntok + tt) * hd + d] = v;
+                            }
+                            if (++tt == ntok) {
+                                tt = 0;
+                                ++bb;
+                            }
+                        }
+                    }
+                }
+                return;
+            }
+        }
         constexpr int RS = NT >= BM ? NT / BM : 1;  // feature rows handled per sweep
         static_assert(NT >= BM, "one lane per token column");
         if (threadIdx.x >= RS * BM) return;
         const int col = threadIdx.x % BM, m = m0 + col;
         if (m >= M) return;
         const int b = m / ntok, t = m - b * ntok;
-        const int rem0 = n0 - 2 * D;
         const f32x2 mr = rowtab[col];  // (0, 1) without a folded LayerNorm
         const float mu = mr[0], rstd = mr[1];
 #pragma unroll 4
