@@ -1340,10 +1340,14 @@ __global__ __launch_bounds__(256) void attn_probs_x3_kernel(const char *__restri
 #pragma unroll
     for (int e = 0; e < 16; ++e) lr[e] = lse2[(int64_t)bh * N + min(q0 + acc_row32(e, h), N - 1)];
     float *out = attn + (int64_t)bh * N * N;
-    const int ktiles = (N + 31) >> 5;
+    // blockIdx.z: a contiguous share of the key tiles (every probability is independent of the others: small batches are cut
+    // along the keys too, so that a one-tile call is more than a dozen workgroups walking the whole row)
+    const int nkt = (N + 31) >> 5, per = (nkt + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int kt0 = (int)blockIdx.z * per, ktiles = min(nkt, kt0 + per);
+    if (kt0 >= ktiles) return;
     bf16x8 kh[NQ], kl[NQ], nh[NQ], nl[NQ];
-    loadrow(Kb, min(r, N - 1), kh, kl);
-    for (int kt = 0; kt < ktiles; ++kt) {
+    loadrow(Kb, min(kt0 * 32 + r, N - 1), kh, kl);
+    for (int kt = kt0; kt < ktiles; ++kt) {
         if (kt + 1 < ktiles) loadrow(Kb, min((kt + 1) * 32 + r, N - 1), nh, nl);
         f32x16 S;
 #pragma unroll
@@ -1604,15 +1608,19 @@ hipError_t launch_attention_probs(int prec, const void *q, const void *k, const 
                                   int n_tokens, int n_pad, int heads, float scale, hipStream_t s, int head_dim) {
     const int qtiles = (n_tokens + 31) / 32;
     const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
+    // split-bf16 kernels: key chunks in grid.z until there are ~512 workgroups (a one-tile call is 12 .. 114 otherwise)
+    const int wgs = (int)(grid.x * grid.y), ktiles = qtiles;
+    const int nz = wgs >= 256 ? 1 : min(ktiles, min(16, (512 + wgs - 1) / wgs));
+    const dim3 gridz(grid.x, grid.y, nz);
     if (head_dim == 128 && prec == 2) {
-        attn_probs_x3_kernel<128><<<grid, block, 0, s>>>((const char *)q, (const char *)k, lse2, attn, n_tokens, n_pad,
-                                                         scale * LOG2E);
+        attn_probs_x3_kernel<128><<<gridz, block, 0, s>>>((const char *)q, (const char *)k, lse2, attn, n_tokens, n_pad,
+                                                          scale * LOG2E);
         return hipGetLastError();
     }
     if (head_dim != 64) return hipErrorInvalidValue;
     if (prec == 2)
-        attn_probs_x3_kernel<64><<<grid, block, 0, s>>>((const char *)q, (const char *)k, lse2, attn, n_tokens, n_pad,
-                                                    scale * LOG2E);
+        attn_probs_x3_kernel<64><<<gridz, block, 0, s>>>((const char *)q, (const char *)k, lse2, attn, n_tokens, n_pad,
+                                                     scale * LOG2E);
     else if (prec)
         attn_probs_f32_kernel<<<grid, block, 0, s>>>((const float *)q, (const float *)k, lse2, attn, n_tokens, n_pad,
                                                      scale * LOG2E);
