@@ -450,7 +450,7 @@ static int run_block(const ocm_vit *h, int i, const Workspace &w, float *x, int 
     if (out_rows && !out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s, h->hd)); }
     if (attn_only) {
         if (out_attn) {
-            { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s, h->hd)); }
+            { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s, h->hd, w.kpart, w.kpart_bytes)); }
             { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s, h->hd)); }
             if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
         }
@@ -517,7 +517,7 @@ static int run_block_folded(const ocm_vit *h, int i, const Workspace &w, float *
         if (out_rows && !out_attn) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_rows(pc, w.q, w.k, query_rows, n_rows, out_rows, batch, n, np, H, scale, s, h->hd)); }
         if (attn_only) {
             if (out_attn) {
-                { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s, h->hd)); }
+                { PROF(OCM_K_ATTN, s); HIP_TRY(launch_attention(pc, w.q, w.k, w.vt, nullptr, w.lse, batch, n, np, H, scale, s, h->hd, w.kpart, w.kpart_bytes)); }
                 { PROF(OCM_K_PROBS, s); HIP_TRY(launch_attention_probs(pc, w.q, w.k, w.lse, out_attn, batch, n, np, H, scale, s, h->hd)); }
                 if (out_rows) { PROF(OCM_K_PROBS, s); HIP_TRY(launch_rows_from_probs(out_attn, query_rows, n_rows, out_rows, batch, n, H, s)); }
             }

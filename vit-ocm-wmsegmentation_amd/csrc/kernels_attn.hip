@@ -1066,15 +1066,17 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
         if (qrow < N) {
             float *dst = part + (((int64_t)blockIdx.z * gridDim.y + bh) * N + qrow) * (HD + 4);
             if (h == 0) *(f32x2 *)(dst + HD) = f32x2{m, lt};
+            if (WANT_O) {
 #pragma unroll
-            for (int db = 0; db < ND; ++db)
+                for (int db = 0; db < ND; ++db)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    f32x4 o;
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = O[db][4 * g + e];
-                    *(f32x4 *)(dst + 32 * db + 8 * g + 4 * h) = o;
-                }
+                        for (int e = 0; e < 4; ++e) o[e] = O[db][4 * g + e];
+                        *(f32x4 *)(dst + 32 * db + 8 * g + 4 * h) = o;
+                    }
+            }
         }
         return;
     }
@@ -1129,15 +1131,17 @@ __global__ __launch_bounds__(256) void attn_merge_x3_kernel(const float *__restr
         const f32x2 ml = *(const f32x2 *)(p + s * stride + HD);
         const float wgt = fast_exp2(ml[0] - m);
         L = fmaf(ml[1], wgt, L);
-        o += *(const f32x4 *)(p + s * stride + c) * wgt;
+        if (ctx) o += *(const f32x4 *)(p + s * stride + c) * wgt;
     }
-    const float inv = 1.0f / L;
-    const int bh = (int)(row / N), q = (int)(row - (int64_t)bh * N), b = bh / H, head = bh - b * H;
-    bf16x4 hi, lo;
-    split4(o * inv, hi, lo);
-    char *dst = ctx + ((int64_t)b * N + q) * (H * HD) * 4 + head * (HD * 4) + sp_off(c);
-    *(bf16x4 *)dst = hi;
-    *(bf16x4 *)(dst + 64) = lo;
+    if (ctx) {
+        const float inv = 1.0f / L;
+        const int bh = (int)(row / N), q = (int)(row - (int64_t)bh * N), b = bh / H, head = bh - b * H;
+        bf16x4 hi, lo;
+        split4(o * inv, hi, lo);
+        char *dst = ctx + ((int64_t)b * N + q) * (H * HD) * 4 + head * (HD * 4) + sp_off(c);
+        *(bf16x4 *)dst = hi;
+        *(bf16x4 *)(dst + 64) = lo;
+    }
     if (lse2 && c == 0) lse2[row] = m + __log2f(L);
 }
 
@@ -1551,18 +1555,23 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
         const dim3 grid8((qtiles + 7) / 8, batch * heads), block8(512);
         // Long sequence, few workgroups (one ViT-S/8 window per call: 60 of them, 73 key tiles each): cut the key range into
         // up to four slices per workgroup and merge (attn_merge_x3_kernel)
-        // (not for a block whose probabilities are returned: their log-sum-exp then comes from the one kernel that also serves
-        // get_last_selfattention's statistics-only pass, so both entry points return the same bits)
-        if (wide && ctx && !lse2 && ksplit_ws && OCM_KNOB(7) == 0) {
+        // (the statistics-only pass of get_last_selfattention takes the same slices, so the log-sum-exp — and with it the returned
+        // probabilities — has the same bits from both entry points)
+        if (wide && ksplit_ws && OCM_KNOB(7) == 0) {
             const int wgs = (int)(grid8.x * grid8.y), ktiles = (n_tokens + 31) / 32;
             // (eight slices of 9-10 tiles measure slower than four of 18-19: 36.6 + 7.4 us against 34.3 + 5.1 us with the merge)
             const int want = wgs <= 64 ? 4 : wgs <= 96 ? 3 : wgs <= 128 ? 2 : 1;
             const int per = (ktiles + want - 1) / want, nslice = (ktiles + per - 1) / per;  // every slice owns >= 1 tile
             const size_t need = (size_t)nslice * batch * heads * n_tokens * (64 + 4) * sizeof(float);
             if (nslice > 1 && need <= ksplit_bytes) {
-                attn_fwd_x3_dma_kernel<true, 8, 2, 64, 3, true><<<dim3(grid8.x, grid8.y, nslice), block8, 0, s>>>(
-                    (const char *)q, (const char *)k, (const char *)vt, (char *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E, 0,
-                    ksplit_ws);
+                if (ctx)
+                    attn_fwd_x3_dma_kernel<true, 8, 2, 64, 3, true><<<dim3(grid8.x, grid8.y, nslice), block8, 0, s>>>(
+                        (const char *)q, (const char *)k, (const char *)vt, (char *)ctx, lse2, n_tokens, n_pad, heads,
+                        scale * LOG2E, 0, ksplit_ws);
+                else
+                    attn_fwd_x3_dma_kernel<false, 8, 2, 64, 3, true><<<dim3(grid8.x, grid8.y, nslice), block8, 0, s>>>(
+                        (const char *)q, (const char *)k, (const char *)vt, (char *)ctx, lse2, n_tokens, n_pad, heads,
+                        scale * LOG2E, 0, ksplit_ws);
                 if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
                 const int64_t rows = (int64_t)batch * heads * n_tokens;
                 attn_merge_x3_kernel<64><<<dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s>>>(
