@@ -198,7 +198,7 @@ def main():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--precision", default="bf16x3", choices=["bf16x3", "bf16", "fp32"],
                     help="operand precision of the contraction kernels. Default: bf16x3 (split-bf16 on the bf16 MFMA), the "
-                         "fastest mode that holds the north star's 1e-3 on every golden weight set")
+                         "fastest mode that holds the north star's 1e-3 on every golden weight set with an unsaturated softmax (DESIGN.md 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-slab", action="store_true", help="skip the sharded 4096^2 slab sweep (BASELINE configs[3]) extra")
     ap.add_argument("--slab-size", type=int, default=4096)

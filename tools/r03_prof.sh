@@ -17,17 +17,20 @@ timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --outp
 {
 echo "== config 3: ViT-B/16 384^2 B=128"; python3 $R/bench.py --arch vit_base --size 384 --batch 128 --steps 5 --warmup 2 --no-cpu-baseline --no-slab 2>/dev/null
 echo "== config 4: slab sweep (default precision)"; python3 $R/tools/sweep_slab.py 2>/dev/null
-echo "== config 5: Swin-T"; python3 $R/tools/bench_swin.py 2>/dev/null
+echo "== config 5: Swin-T (bf16 / split-bf16 / fp32)"; for p in bf16 bf16x3 fp32; do python3 $R/tools/bench_swin.py --precision $p 2>/dev/null; done
 echo "== one tile per call"; python3 $R/tools/latency_b1.py bf16x3 2>/dev/null
 } > $O/other_configs.txt 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_vitb -- python3 $R/bench.py --arch vit_base --size 384 --batch 128 --steps 3 --warmup 1 --no-cpu-baseline --no-slab > /dev/null 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_slab -- python3 $R/tools/sweep_slab.py --reps 1 > /dev/null 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_slab -- python3 $R/tools/sweep_slab.py --reps 1 > /dev/null 2>&1
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_slab -- python3 $R/tools/sweep_slab.py --reps 1 > /dev/null 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_swin -- python3 $R/tools/bench_swin.py --precision bf16x3 --steps 5 > /dev/null 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1 -- python3 $R/tools/b1_loop.py vit_small 16 224 100 > /dev/null 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_b1_s8 -- python3 $R/tools/b1_loop.py vit_small 8 384 50 > /dev/null 2>&1
 cd $R
 for d in pmc_fetch pmc_write pmc_sq1 pmc_sq2 pmc_tcc pmc_fetch_slab pmc_write_slab; do python3 tools/pmc_summary.py $O/$d > $O/$d.txt 2>&1 < /dev/null; done
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-for n in vitb slab; do find $O/prof_$n -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_$n.csv \; ; done
-rm -rf $O/prof $O/prof_vitb $O/prof_slab $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2 $O/pmc_tcc $O/pmc_fetch_slab $O/pmc_write_slab
+for n in vitb slab swin b1 b1_s8; do find $O/prof_$n -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats_$n.csv \; ; done
+rm -rf $O/prof $O/prof_vitb $O/prof_slab $O/prof_swin $O/prof_b1 $O/prof_b1_s8 $O/pmc_fetch $O/pmc_write $O/pmc_sq1 $O/pmc_sq2 $O/pmc_tcc $O/pmc_fetch_slab $O/pmc_write_slab
 ls -la $O | head -40
 tail -c 400 $O/bench.json < /dev/null

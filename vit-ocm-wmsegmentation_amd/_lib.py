@@ -18,7 +18,7 @@ OCM_PREC_FP32 = 1
 OCM_PREC_BF16X3 = 2
 OCM_SWIN_OPT_FUSE_MLP = 0
 PRECISIONS = {"bf16": OCM_PREC_BF16, "fp32": OCM_PREC_FP32, "bf16x3": OCM_PREC_BF16X3}
-DEFAULT_PRECISION = "bf16x3"  # the mode that holds the north star's 1e-3 on every golden weight set
+DEFAULT_PRECISION = "bf16x3"  # holds the north star's 1e-3 on every golden weight set with an unsaturated softmax
 OCM_LN_F32, OCM_LN_BF16, OCM_LN_SPLIT = 0, 1, 2
 OCM_OPT_FUSE_LN = 0  # ocm_vit_set_option: 0 auto, 1 never, 2 always
 OCM_OPT_FOLD_LN = 1  # 0 auto (on for split-bf16 engines), 1 never
