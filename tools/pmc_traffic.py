@@ -17,13 +17,13 @@ CLASSES = {
         "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2>, sp32, false, 48,",
         "proj_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2>, sp32, false, 12,",
         "qkv_gemm": "qkv_dma_kernel<GemmCfg<128, 128, 2, 4>, sp32, 12, 2>",
-        "attention": "attn_fwd_x3_dma_kernel<true, 4, 3>",
+        "attention": "attn_fwd_x3_dma_kernel<true, 4, 3,",
         "patch_embed": "gemm_kernel<GemmCfg<64, 128, 2, 2>, sp32, false, 24, PatchLoader<",
     },
     # config 4 (ViT-S/8 slab sweep, 20-21 windows of 2305 tokens per launch): summaries of tools/sweep_slab.py runs
     "slab_bf16x3": {
-        "attention": "attn_fwd_x3_dma_kernel<true, 8, 2>",
-        "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 48, 2, EpiResidStats<",  # 128 x 128 tiles at this size
+        "attention": "attn_fwd_x3_dma_kernel<true, 8, 2,",
+        "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 48, 2, EpiLinear<1",  # 128 x 128 tiles, LayerNorm kernels at this size
         "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 12, 2, EpiL",
     },
 }
