@@ -21,14 +21,19 @@ int ocm_wt_mask();  // kernels_gemm.hip
 #ifndef OCM_SMALLM_STAGES
 #define OCM_SMALLM_STAGES 4
 #endif
-// ... and up to how many rows they are chosen (tried 4096 for one ViT-S/8 window of 384^2 per call, 2305 rows on 111 .. 444
-// workgroups: attn.qkv 18.8 -> 21.8 us, mlp.fc1 16.2 -> 17.5, attn.proj 10.9 -> 9.8 — the register-staged loop stays there)
-constexpr int OCM_SMALLM_ROWS = 1024;
+// ... and up to how many rows they are chosen: 4096 covers one ViT-S/8 window of 384^2 per call (2305 rows, 111 .. 444
+// workgroups). With FOUR waves per tile the register-staged loop was faster there (attn.qkv 18.8 against 21.8 us, mlp.fc1 16.2
+// against 17.5); with eight the LDS-DMA loop wins (the one-window forward 1.42 -> 1.28 ms)
+constexpr int OCM_SMALLM_ROWS = 4096;
 typedef GemmCfg<128, 128, 2, 2> Cfg128x128;
 // the qkv projection runs the same tile with 8 waves (32x64 MFMA sub-tiles per wave): two waves per SIMD inside
 // one workgroup overlap its heavier scatter epilogue with the other waves' MFMAs (29.0 -> 25.8 us at ViT-S, B=64)
 typedef GemmCfg<128, 128, 2, 4> Cfg128x128q;
 typedef GemmCfg<64, 128, 2, 2> Cfg64x128;
+// the same tile on eight wavefronts (32 x 32 each) for the one-tile-per-call forwards: with ONE workgroup per CU a lone wave per
+// SIMD waits out every LDS read before its MFMAs (850 cycles per K step for 384 of MFMA, tools/stamps_b1.py); two waves per SIMD
+// take turns
+typedef GemmCfg<64, 128, 2, 4> Cfg64x128w;
 typedef GemmCfg<64, 64, 2, 2> Cfg64x64;
 // 8 waves, one workgroup per CU: half the L2->LDS bytes per output element of 128x128. Pays off once the
 // problem has at least two full rounds of such tiles (ViT-B at 384^2, the ViT-S/8 slab windows); below
@@ -399,7 +404,7 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
         // fc2 23.1 -> 16.7 us on 64x64 tiles with a 4-deep ring, proj 8.3 -> 7.6 us)
         if (M <= OCM_SMALLM_ROWS && OCM_KNOB(0) == 0) {
             if (K >= 1024 && N % 64 == 0) return launch_gemm_dma<Cfg64x64, E, 4>(a, K, w, K, M, N, K, epi, s);
-            if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, OCM_SMALLM_STAGES>(a, K, w, K, M, N, K, epi, s);
+            if (N % 128 == 0) return launch_gemm_dma<Cfg64x128w, E, OCM_SMALLM_STAGES>(a, K, w, K, M, N, K, epi, s);
         }
         if (big_tiles_pay(M, N, K))  // ViT-B at 384^2: 256x256 tiles, one 8-wave workgroup per CU (fc1 1020 -> 944 us)
             return launch_gemm_dma<Cfg256x256, E, 2>(a, K, w, K, M, N, K, epi, s);
@@ -472,7 +477,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_dma_splitk_kernel(const E *__res
 template <class E>
 static hipError_t launch_linear_splitk(const E *a, const E *w, const float *bias, const float *resid, float *x, int M, int N,
                                        int K, hipStream_t s, const StatsOut &so) {
-    typedef Cfg64x64 Cfg;
+    typedef Cfg64x64 Cfg;  // (the eight-wave 64 x 128 tile halves the workgroups: 0.628 -> 0.641 ms per one-tile forward)
     constexpr int NSTAGE = 4, KS = 12;  // K / OCM_SPLITK = 384 elements = 12 steps (ViT-S mlp.fc2); other depths: no split
     constexpr int LDS = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
     auto kern = gemm_dma_splitk_kernel<Cfg, E, KS, NSTAGE>;
@@ -976,7 +981,7 @@ hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E
 #endif
             if (OCM_KNOB(3) == 0) {
                 // few rows (one tile per call): the DMA loop's shorter prologue shows (B = 1 forward 1.03 -> 1.01 ms)
-                if (M <= OCM_SMALLM_ROWS) return launch_qkv_dma<Cfg64x128, E, OCM_SMALLM_STAGES>(a, w, M, D, eqk, ev, s);
+                if (M <= OCM_SMALLM_ROWS) return launch_qkv_dma<Cfg64x128w, E, OCM_SMALLM_STAGES>(a, w, M, D, eqk, ev, s);
                 // ViT-B sizes: 256 x 256 tiles halve the bytes through L2 (384^2 B = 128: 755 -> 715 us per launch)
                 if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_dma<Cfg256x256, E, 2>(a, w, M, D, eqk, ev, s);
                 // the 8-wave 128 x 128 tile on the LDS-DMA loop (ViT-S/16 B = 64: 46.6 -> 41.8 us per launch, +2 % end
