@@ -1137,6 +1137,9 @@ hipError_t launch_patch_e(const PatchArgs &pa, const E *w, const float *bias, co
     const int P = pa.hp * pa.wp, M = pa.batch * P, K = pa.chans * pa.p * pa.p;
     PatchLoader<E> al{pa.image, pa.sb, pa.sc, pa.sy, pa.origins, P, pa.wp, pa.p, pa.p * pa.p};
     EpiPatch epi{bias, pos, x, M, P, P + 1, dim, pa.mask, pa.mask_tok, so};
+    // one tile per call (a dozen workgroups): eight wavefronts per tile, two per SIMD (see Cfg64x128w)
+    if constexpr (Elem<E>::MODE == 2)
+        if (dim % 128 == 0 && M > 64 && M <= 1024) return launch_gemm<Cfg64x128w, E, false>(al, w, K, M, dim, K, epi, s);
     if (dim % 128 == 0 && M > 64) return launch_gemm<Cfg64x128, E, false>(al, w, K, M, dim, K, epi, s);
     return launch_gemm<Cfg64x64, E, false>(al, w, K, M, dim, K, epi, s);
 }
