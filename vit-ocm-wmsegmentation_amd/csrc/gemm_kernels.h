@@ -392,6 +392,7 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             case 9: if (N % 128 == 0) return launch_gemm_dma<Cfg64x128, E, 4>(a, K, w, K, M, N, K, epi, s); break;
             case 10: if (N % 64 == 0) return launch_gemm_dma<Cfg64x64, E, 4>(a, K, w, K, M, N, K, epi, s); break;
             case 11: if (N == 384) return launch_gemm_dma<Cfg128x192, E, 3>(a, K, w, K, M, N, K, epi, s); break;
+            case 12: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128q, E, 2>(a, K, w, K, M, N, K, epi, s); break;  // 8 waves
             default: break;
         }
 #endif
@@ -414,8 +415,13 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
         // in the forward, mlp.fc2 64 -> 49 us, attn.proj 28.5 -> 21.5 us against the full-row GEMM + LayerNorm kernels
         if (N % 192 == 0 && N / 192 <= 2 && M >= 4096 && (long)((M + 127) / 128) * ((N + 127) / 128) < 512)
             return launch_gemm_dma<Cfg128x192, E, 3>(a, K, w, K, M, N, K, epi, s);
-        if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512)
+        if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512) {
+            // wide outputs (mlp.fc1): the same tile on eight wavefronts, four per SIMD with two workgroups per CU (58.0 -> 56.2 us
+            // in the forward on one box, 53.0 -> 51.8 on another; the N = 384 layers lose on it: fc2 56 -> 62, proj 26 -> 27, and
+            // so does mlp.fc1 at 48 k rows: slab sweep 530 -> 533 ms)
+            if (N >= 1024 && M < 32768) return launch_gemm_dma<Cfg128x128q, E, 2>(a, K, w, K, M, N, K, epi, s);
             return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
+        }
         // Swin-T's narrow stages (N = 96, 192, 288, 576 at 2e5 .. 8e5 rows): tiles that divide N exactly on the LDS-DMA
         // loop instead of 64 x 64 register-staged tiles with a ragged last column (these GEMMs are bound by the 4-byte
         // activations they stream, not by the matrix pipe)
