@@ -60,16 +60,18 @@ def test_layernorm_split_out(lib, dev, rows, dim):
     assert (err <= ref.abs() * 2 ** -16 + 2e-5).all(), err.max().item()  # fp32 LayerNorm, then 2^-17 pairs
 
 
-# The shapes reach every split-bf16 GEMM the BASELINE configurations dispatch (kernels_gemm.hip::launch_linear_mode):
-#   (12608, 1536, 384)  config 2 fc1: 1188 tiles -> gemm_dma_kernel<128x128>, two workgroups per CU
-#   (12608, 384, *)     config 2 proj / fc2 un-fused: 64x128 register-staged
+# The shapes reach every split-bf16 GEMM the BASELINE configurations dispatch (gemm_kernels.h::launch_linear_epi):
+#   (12608, 1536, 384)  config 2 fc1: 1188 tiles, N >= 1024 -> gemm_dma_kernel<128x128, eight waves>, two workgroups per CU
+#   (12608, 384, *)     config 2 proj / fc2: gemm_dma_kernel<128x192> on a three-stage ring
 #   (32768, 1024, 768)  config 3: 512 tiles of 256x256 -> gemm_dma_kernel<256x256>, banded epilogue
-#   (24576, 384, 1536)  config 4 fc2 at 10-11 windows per forward and up: 576 tiles -> un-fused gemm_dma_kernel<128x128>, K = 48 steps
-#   (1000 / 333 / 70 / 64 rows): the one-tile-per-call DMA kernels (64x128 two-stage, 64x64 four-stage) and tails
+#   (24576, 384, 1536)  config 4 fc2 (48 K steps) -> gemm_dma_kernel<128x192> as well since round 3
+#   (16384, 512, 384)   512 tiles of 128x128, N < 1024 and not a multiple of 192 -> gemm_dma_kernel<128x128, four waves>
+#                       (config 4's fc1 takes it at 48 k rows: tests/test_bench_configs_gpu.py)
+#   (1000 / 333 / 70 / 64 rows): the one-tile-per-call DMA kernels (64x128 on eight waves, 64x64 four-stage) and tails
 #   (6000, 288 / 96, 96), (5000, 576 / 192, *): Swin-T's narrow stages in split-bf16 mode -> gemm_dma_kernel<128x96> / <128x192>
 @pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (12608, 1536, 384), (333, 384, 1536), (70, 96, 192),
                                    (12608, 384, 384), (64, 192, 64), (32768, 1024, 768), (24576, 384, 1536),
-                                   (6000, 288, 96), (6000, 96, 384), (5000, 576, 192), (5000, 192, 768)])
+                                   (6000, 288, 96), (6000, 96, 384), (5000, 576, 192), (5000, 192, 768), (16384, 512, 384)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_linear_x3(lib, dev, M, N, K, epi):
     a = _rand((M, K), dev, 40)

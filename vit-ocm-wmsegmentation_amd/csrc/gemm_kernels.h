@@ -413,7 +413,9 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
         // tiles, one 8-wave workgroup per CU on a three-stage LDS-DMA ring. Per K step 40 KiB of operands for 1152 cycles
         // of MFMA per SIMD (56 KiB for the 64 x 384 full-row tile, 64 KiB for two 64 x 128 tiles): ViT-S/16 at B = 64,
         // in the forward, mlp.fc2 64 -> 49 us, attn.proj 28.5 -> 21.5 us against the full-row GEMM + LayerNorm kernels
-        if (N % 192 == 0 && N / 192 <= 2 && M >= 4096 && (long)((M + 127) / 128) * ((N + 127) / 128) < 512)
+        // (also past 512 tiles of 128 x 128: at 48 k rows — the 4096^2 slab sweep — 1137 such tiles are 2.2 rounds of 512 slots,
+        // 758 tiles of 128 x 192 are 2.96 rounds of 256: sweep 557.7 -> 551.3 ms)
+        if (N % 192 == 0 && N / 192 <= 2 && M >= 4096)
             return launch_gemm_dma<Cfg128x192, E, 3>(a, K, w, K, M, N, K, epi, s);
         if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512) {
             // wide outputs (mlp.fc1): the same tile on eight wavefronts, four per SIMD with two workgroups per CU (58.0 -> 56.2 us
