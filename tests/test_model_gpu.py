@@ -398,17 +398,25 @@ def test_one_tile_calls_replay_a_graph_automatically(dev):
     feat_want = model.get_intermediate_feat(x, 2)
     rows_want = model.get_last_attention_rows(x, torch.tensor([0, 5], dtype=torch.int32, device=dev))
     model.auto_graph = True
-    for _ in range(3):  # capture, then replays
+    assert torch.equal(model.get_last_selfattention(x), want[0])  # first sighting of this (shape, outputs): launch by launch
+    assert len(model.__dict__.get("_auto_graphs", {})) == 0
+    for _ in range(3):  # second sighting captures, then replays
         assert torch.equal(model.get_last_selfattention(x), want[0])
         assert torch.equal(model.get_last_selfattention(x2), want[1])
     assert len(model._auto_graphs) == 1
-    got = model.get_intermediate_feat(x, 2)
+    for _ in range(3):
+        got = model.get_intermediate_feat(x, 2)
+    assert len(model._auto_graphs) == 2
     for a, b in zip(feat_want, got):
         for u, v in zip(a, b):
             assert torch.equal(u, v)
     qr = torch.tensor([0, 5], dtype=torch.int32, device=dev)
-    for _ in range(2):
+    for _ in range(3):
         assert torch.equal(model.get_last_attention_rows(x, qr), rows_want)
+    n_graphs = len(model._auto_graphs)
+    for _ in range(3):  # a new index tensor per call is never captured
+        assert torch.equal(model.get_last_attention_rows(x, torch.tensor([0, 5], dtype=torch.int32, device=dev)), rows_want)
+    assert len(model._auto_graphs) == n_graphs
     # returned tensors are copies: a later call does not overwrite them
     a = model.get_last_selfattention(x)
     b = model.get_last_selfattention(x2)

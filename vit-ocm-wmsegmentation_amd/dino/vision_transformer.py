@@ -255,6 +255,7 @@ class VisionTransformer(nn.Module):
         st["_engines"], st["_pos_cache"] = {}, {}
         st.pop("_auto_graphs", None)
         st.pop("_param_slots", None)
+        st.pop("_auto_seen", None)
         return st
 
     # ---- engine management ------------------------------------------------------------------
@@ -382,7 +383,7 @@ class VisionTransformer(nn.Module):
 
     # One tile per call — what the reference's loops issue (eval.py:126-171, sw_processing.py:235-258) — is bound by the 60-odd
     # kernel launches of a forward rather than by the kernels. Such calls (eval mode, at most AUTO_GRAPH_TOKENS token rows) are
-    # therefore replayed as a HIP graph without the caller asking: the first call of a given (shape, outputs) captures the
+    # therefore replayed as a HIP graph without the caller asking: the second call of a given (shape, outputs) captures the
     # launch sequence on fixed buffers, later calls copy the tile in, replay with one launch and return copies. Same kernels,
     # same order, same bits; every call still compares the parameters' (address, version) signature, so a load_state_dict
     # or an in-place update re-captures. `model.auto_graph = False` switches it off.
@@ -397,10 +398,15 @@ class VisionTransformer(nn.Module):
         npatch = (w // eng.p) * (h // eng.p)
         if (self.auto_graph and not self.training and not self.__dict__.get("_graph_suspended")
                 and x.shape[0] * (npatch + 1) <= self.AUTO_GRAPH_TOKENS and not torch.cuda.is_current_stream_capturing()):
-            return self._run_auto_graph(x, eng, kw)
+            out = self._run_auto_graph(x, eng, kw)
+            if out is not None:
+                return out
         return eng.forward(x, self._pos_for(npatch, w, h, x.device), **kw)
 
     def _run_auto_graph(self, x, eng, kw):
+        """The replayed result, or None when this call should run launch by launch: a (shape, outputs, query_rows tensor)
+        combination is captured the SECOND time it is seen — a loop over differently sized tiles, or one that builds a new
+        query_rows tensor per call, never pays for warm-ups and captures it would not reuse."""
         qr = kw.get("query_rows")
         key = (tuple(x.shape), x.device, id(eng), self.__dict__.get("_engine_epoch", 0), self._precision, self._gray_fold,
                self.pos_embed.data_ptr(),
@@ -408,6 +414,13 @@ class VisionTransformer(nn.Module):
         cache = self.__dict__.setdefault("_auto_graphs", {})
         ent = cache.get(key)
         if ent is None:
+            seen = self.__dict__.setdefault("_auto_seen", {})
+            if key not in seen:
+                if len(seen) >= 64:
+                    seen.clear()
+                seen[key] = qr  # (keeps the index tensor alive, so its id cannot be reused by another one)
+                return None
+            del seen[key]
             for k in [k for k in cache if k[2:4] != key[2:4]]:  # captures of engines / parameter uploads that are gone
                 del cache[k]
             while len(cache) >= self.AUTO_GRAPH_ENTRIES:
