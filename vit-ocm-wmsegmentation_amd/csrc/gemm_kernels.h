@@ -449,9 +449,11 @@ reg_staged:
     return launch_gemm<Cfg64x64, E, false>(al, w, K, M, N, K, epi, s);
 }
 
+// (external linkage: kernels_gemm_inst.hip instantiates the activation-output modes of the split-bf16 type in an object of
+// their own, so that the library's longest compile is not twice as long as the others)
 template <int MODE, class E>
-static hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, const float *resid, void *out, int M,
-                                     int N, int K, hipStream_t s, const LnFold &ln = LnFold()) {
+hipError_t launch_linear_mode(const E *a, const E *w, const float *bias, const float *resid, void *out, int M,
+                              int N, int K, hipStream_t s, const LnFold &ln = LnFold()) {
     EpiLinear<MODE, E> epi{bias, resid, out, M, N, N};
     epi.wt = ocm_wt_mask() & 1;
     if (ln.stats) {  // folded LayerNorm: the bias travels in ln.d, the accumulator starts at zero

@@ -1,6 +1,8 @@
 // kernels_gemm_inst.hip — explicit instantiations of gemm_kernels.h for ONE operand element type (OCM_INST_E: 0 = bf16,
-// 1 = float, 2 = sp32) and ONE half of the entry points (OCM_INST_PART: 0 = nn.Linear, 1 = fused residual + LayerNorm, qkv
-// projection, patch embedding). The Makefile compiles this file six times; nothing else instantiates the GEMM kernels.
+// 1 = float, 2 = sp32) and ONE share of the entry points (OCM_INST_PART: 0 = nn.Linear, 1 = fused residual + LayerNorm, qkv
+// projection, patch embedding, 2 = the activation-output epilogues of nn.Linear for sp32 only, split off part 0 because that
+// object took twice as long as any other). The Makefile compiles this file seven times; nothing else instantiates the GEMM
+// kernels.
 #include "gemm_kernels.h"
 
 #if OCM_INST_E == 0
@@ -11,7 +13,18 @@ typedef float InstE;
 typedef sp32 InstE;
 #endif
 
-#if OCM_INST_PART == 0
+#if OCM_INST_PART == 2
+template hipError_t launch_linear_mode<2, InstE>(const InstE *, const InstE *, const float *, const float *, void *, int, int, int,
+                                                 hipStream_t, const LnFold &);
+template hipError_t launch_linear_mode<3, InstE>(const InstE *, const InstE *, const float *, const float *, void *, int, int, int,
+                                                 hipStream_t, const LnFold &);
+#elif OCM_INST_PART == 0
+#if OCM_INST_E == 2  // instantiated in part 2
+extern template hipError_t launch_linear_mode<2, InstE>(const InstE *, const InstE *, const float *, const float *, void *, int,
+                                                        int, int, hipStream_t, const LnFold &);
+extern template hipError_t launch_linear_mode<3, InstE>(const InstE *, const InstE *, const float *, const float *, void *, int,
+                                                        int, int, hipStream_t, const LnFold &);
+#endif
 #if defined(OCM_GEMM_STAMPS) && OCM_INST_E == 2
 // development only: the cycle stamps of THIS translation unit's kernels (nn.Linear, split-bf16); g_stamps is per object
 extern "C" int ocm_debug_stamps_linear(unsigned long long *host, int n) {
