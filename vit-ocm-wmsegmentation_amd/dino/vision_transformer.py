@@ -436,8 +436,12 @@ class VisionTransformer(nn.Module):
                         self._run(xs, **kw)
                 cur.wait_stream(side)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                # thread-local capture: HIP calls of the caller's other threads (loaders, pinned copies) stay legal
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     out = self._run(xs, **kw)
+            except RuntimeError:  # a capture this process cannot make: run launch by launch from now on
+                self.auto_graph = False
+                return None
             finally:
                 self.__dict__["_graph_suspended"] = False
             # everything the captured launches point at stays alive with the capture
