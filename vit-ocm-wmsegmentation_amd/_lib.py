@@ -149,6 +149,8 @@ SIGNATURES = {
     "ocm_swin_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_size_t, C.c_void_p]),
     "ocm_swin_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "ocm_op_swin_lnqkv": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "ocm_op_swin_mlp": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "ocm_op_swin_window_attention": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,

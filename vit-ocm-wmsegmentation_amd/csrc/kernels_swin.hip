@@ -897,6 +897,147 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void swin_mlp_x3_kernel(f
         }
 }
 
+// layernorm_before + the fused q | k | v projection of a narrow-stage SwinLayer in one kernel (split-bf16, C = 96 / 128):
+//     qkv (T, 3C) pairs = LayerNorm(x) Wqkv^T + b                                    modeling_swin.py SwinLayer.forward :641, SwinSelfAttention :430-432
+// The first half of swin_mlp_x3_kernel: a wavefront owns 32 tokens, normalises their rows in registers into the B operand
+// x^T, and walks the 3C / 32 chunks of 32 output features — W rows in pi order through a three-stage LDS-DMA ring — whose
+// accumulator registers (eight consecutive features per lane and run) leave as 16-byte pieces of the tokens' pair rows.
+// HBM traffic: x once in, qkv once out (1.23 GB at 8e5 rows, against 0.6 + 1.23 GB for LayerNorm kernel + GEMM, the
+// latter at 2.9 TB/s on three-K-step tiles).
+template <int CG, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void swin_lnqkv_x3_kernel(const float *__restrict__ x, const float *__restrict__ gam,
+                                                                  const float *__restrict__ bet, const char *__restrict__ w,
+                                                                  const float *__restrict__ bias, char *__restrict__ qkv, int T,
+                                                                  float eps) {
+    constexpr int C = CG * 32, NF = 3 * CG, STAGE = CG * 4096, NSTAGE = 3, PIECES = 4 * CG, PPW = PIECES / NW, NS = 2 * CG;
+    static_assert(PIECES % NW == 0, "the wavefronts share the pieces of a step evenly");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    float *bs = (float *)(smem + NSTAGE * STAGE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int tok0 = (blockIdx.x * NW + wave) * 32;
+    const bool live = tok0 + r < T;
+    const size_t tok = (size_t)min(tok0 + r, T - 1);
+    for (int i = tid; i < 3 * C; i += NW * 64) bs[i] = bias[i];
+    int voff[PPW];
+    {
+        const int lrow = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int jj = 0; jj < PPW; ++jj) {
+            const int pc = jj * NW + wave, rho = (pc & 3) * 8 + lrow;
+            voff[jj] = rho * (C * 4) + (pc >> 2) * 128 + ((slot ^ ((rho >> 1) & 7)) << 4);
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, (unsigned)(3 * C * C * 4), 0x00020000);
+#define OCM_QKV_DMA(j, st)                                                                                              \
+    do {                                                                                                                \
+        _Pragma("unroll") for (int jj = 0; jj < PPW; ++jj)                                                              \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (lds_ptr)(smem + (st) * STAGE + (jj * NW + wave) * 1024), 16, \
+                                                     voff[jj], (j) * (32 * C * 4), 0, 0);                               \
+    } while (0)
+#else
+#define OCM_QKV_DMA(j, st) (void)0
+#endif
+    OCM_QKV_DMA(0, 0);
+    OCM_QKV_DMA(1, 1);
+    bf16x8 xh[NS], xl[NS];
+    {
+        const float *xr = x + tok * C + 8 * h;
+        f32x4 v[NS][2];
+        float sum = 0.f;
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            v[sI][0] = *(const f32x4 *)(xr + 16 * sI);
+            v[sI][1] = *(const f32x4 *)(xr + 16 * sI + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += v[sI][0][e] + v[sI][1][e];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / C);
+        float var = 0.f;
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d0 = v[sI][0][e] - mean, d1 = v[sI][1][e] - mean;
+                var = fmaf(d0, d0, fmaf(d1, d1, var));
+            }
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = rsqrtf(var * (1.0f / C) + eps);
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            const f32x4 g0 = *(const f32x4 *)(gam + 16 * sI + 8 * h), g1 = *(const f32x4 *)(gam + 16 * sI + 8 * h + 4);
+            const f32x4 e0 = *(const f32x4 *)(bet + 16 * sI + 8 * h), e1 = *(const f32x4 *)(bet + 16 * sI + 8 * h + 4);
+            split8((v[sI][0] - mean) * rstd * g0 + e0, (v[sI][1] - mean) * rstd * g1 + e1, xh[sI], xl[sI]);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    const int pr = pi_row(r);
+    char *orow = qkv + tok * (3 * C * 4);
+    int sc = 0, si = 2;
+    for (int j = 0; j < NF; ++j) {
+        if (j + 1 < NF)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (j + 2 < NF) OCM_QKV_DMA(j + 2, si);
+        const char *Ws = smem + sc * STAGE;
+        f32x16 S;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] = 0.f;
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            const char *img = Ws + (sI >> 1) * 4096;
+            const bf16x8 ah = *(const bf16x8 *)(img + lds_off(pr, (sI & 1) * 2 + h));
+            const bf16x8 al = *(const bf16x8 *)(img + lds_off(pr, 4 + (sI & 1) * 2 + h));
+            S = mfma32x3(ah, al, xh[sI], xl[sI], S);
+        }
+        // register e of lane half h = feature 32 j + key_of_reg(e, h): two runs of eight -> two 16-byte pieces per half
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const float *bp = bs + 32 * j + 16 * s2 + 8 * h;
+            const f32x4 c0 = *(const f32x4 *)bp, c1 = *(const f32x4 *)(bp + 4);
+            f32x4 u0, u1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                u0[e] = S[8 * s2 + e] + c0[e];
+                u1[e] = S[8 * s2 + 4 + e] + c1[e];
+            }
+            bf16x8 ph, pl;
+            split8(u0, u1, ph, pl);
+            if (live) {
+                char *p = orow + j * 128 + (16 * s2 + 8 * h) * 2;
+                *(bf16x8 *)p = ph;
+                *(bf16x8 *)(p + 64) = pl;
+            }
+        }
+        sc = sc == NSTAGE - 1 ? 0 : sc + 1;
+        si = si == NSTAGE - 1 ? 0 : si + 1;
+    }
+#undef OCM_QKV_DMA
+}
+
+bool swin_lnqkv_fused_supported(int prec, int C) { return prec == 2 && (C == 96 || C == 128); }
+
+hipError_t launch_swin_lnqkv(int prec, const float *x, const float *g, const float *be, const void *w, const float *bias,
+                             void *qkv, size_t T, int C, float eps, hipStream_t s) {
+    if (!swin_lnqkv_fused_supported(prec, C) || T == 0 || T > 0x7fffffffu) return hipErrorInvalidValue;
+    constexpr int NW = 4;
+    const dim3 grid((unsigned)((T + NW * 32 - 1) / (NW * 32))), block(NW * 64);
+    const int lds = 3 * (C / 32 * 4096) + 3 * C * 4;
+    if (C == 96)
+        swin_lnqkv_x3_kernel<3, NW><<<grid, block, lds, s>>>(x, g, be, (const char *)w, bias, (char *)qkv, (int)T, eps);
+    else
+        swin_lnqkv_x3_kernel<4, NW><<<grid, block, lds, s>>>(x, g, be, (const char *)w, bias, (char *)qkv, (int)T, eps);
+    return hipGetLastError();
+}
+
 bool swin_mlp_fused_supported(int prec, int C, int hidden) { return prec == 2 && hidden == 4 * C && (C == 96 || C == 128); }
 
 hipError_t launch_swin_mlp(int prec, float *x, const float *g, const float *be, const void *w1, const float *b1,

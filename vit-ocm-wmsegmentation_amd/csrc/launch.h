@@ -141,6 +141,10 @@ hipError_t launch_swin_bias_perm(const float *table, float *perm, float *dense, 
 hipError_t launch_swin_window_attention(int prec, const void *qkv, int ld, void *ctx, int ldc, const float *bias_perm,
                                         const float *bias_dense, int batch, int H, int W, int ws, int shift, int heads,
                                         hipStream_t s);
+// layernorm_before + q | k | v projection of a narrow-stage SwinLayer in one kernel (split-bf16, C = 96 / 128)
+bool swin_lnqkv_fused_supported(int prec, int C);
+hipError_t launch_swin_lnqkv(int prec, const float *x, const float *g, const float *be, const void *w, const float *bias,
+                             void *qkv, size_t T, int C, float eps, hipStream_t s);
 // SwinLayer's MLP half in one kernel (split-bf16, C = 96 / 128, hidden = 4 C): x += fc2(gelu(fc1(LayerNorm(x))))
 bool swin_mlp_fused_supported(int prec, int C, int hidden);
 hipError_t launch_swin_mlp(int prec, float *x, const float *g, const float *be, const void *w1, const float *b1,

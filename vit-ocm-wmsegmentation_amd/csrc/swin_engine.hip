@@ -301,10 +301,15 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
         for (size_t b = 0; b < h->stages[st].layers.size(); ++b) {
             const LayerP &lp = h->stages[st].layers[b];
             const int shift = (b % 2 == 1 && H > ws) ? ws / 2 : 0;  // set_shift_and_window_size :576-582
-            HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), w.xn, T, C, Kc, eps,
-                                   false, 0, 0, s));
-            HIP_TRY(swin_linear(pc, w.xn, Kc, h->ptr<char>(lp.wqkv), h->ptr<float>(lp.bqkv), nullptr, w.qkv, 3 * C,
-                                     (int)T, 3 * C, Kc, OCM_EPI_BIAS_BF16, s));
+            if (h->fuse_mlp && swin_lnqkv_fused_supported(pc, C)) {  // narrow stages: no normalised copy of x in HBM
+                HIP_TRY(launch_swin_lnqkv(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), h->ptr<char>(lp.wqkv),
+                                          h->ptr<float>(lp.bqkv), w.qkv, T, C, eps, s));
+            } else {
+                HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), w.xn, T, C, Kc, eps,
+                                       false, 0, 0, s));
+                HIP_TRY(swin_linear(pc, w.xn, Kc, h->ptr<char>(lp.wqkv), h->ptr<float>(lp.bqkv), nullptr, w.qkv, 3 * C,
+                                         (int)T, 3 * C, Kc, OCM_EPI_BIAS_BF16, s));
+            }
             HIP_TRY(launch_swin_window_attention(pc, w.qkv, 3 * C, w.ctx, Kc, h->ptr<float>(lp.bias_perm),
                                                  h->ptr<float>(lp.bias_dense), batch, H, H, ws, shift, heads, s));
             HIP_TRY(swin_linear(pc, w.ctx, Kc, h->ptr<char>(lp.wo), h->ptr<float>(lp.bo), x, x, C, (int)T, C, Kc,
@@ -347,6 +352,19 @@ extern "C" int ocm_swin_set_option(ocm_swin_t *h, int32_t option, int32_t value)
     if (option != OCM_SWIN_OPT_FUSE_MLP) return fail(OCM_EINVAL, "unknown Swin option %d", option);
     if (value != 0 && value != 1) return fail(OCM_EINVAL, "OCM_SWIN_OPT_FUSE_MLP takes 0 or 1, got %d", value);
     h->fuse_mlp = value != 0;
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_swin_lnqkv(int32_t precision, const float *x, const float *gamma, const float *beta, const void *w,
+                                 const float *bias, void *qkv, int64_t tokens, int32_t channels, float eps, void *stream) {
+    if (!x || !gamma || !beta || !w || !bias || !qkv) return fail(OCM_EINVAL, "null argument");
+    const int pc = precision == OCM_PREC_FP32 ? 1 : precision == OCM_PREC_BF16X3 ? 2 : precision == OCM_PREC_BF16 ? 0 : -1;
+    if (pc < 0) return fail(OCM_EINVAL, "bad precision");
+    if (tokens <= 0 || tokens > 0x7fffffffLL) return fail(OCM_EINVAL, "bad token count %lld", (long long)tokens);
+    if (!swin_lnqkv_fused_supported(pc, channels))
+        return fail(OCM_EINVAL, "the fused LayerNorm + qkv projection is built for split-bf16 operands and 96 or 128 channels "
+                                "(got precision %d, %d channels)", precision, channels);
+    HIP_TRY(launch_swin_lnqkv(pc, x, gamma, beta, w, bias, qkv, (size_t)tokens, channels, eps, (hipStream_t)stream));
     return OCM_OK;
 }
 
