@@ -413,10 +413,14 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
         // tiles, one 8-wave workgroup per CU on a three-stage LDS-DMA ring. Per K step 40 KiB of operands for 1152 cycles
         // of MFMA per SIMD (56 KiB for the 64 x 384 full-row tile, 64 KiB for two 64 x 128 tiles): ViT-S/16 at B = 64,
         // in the forward, mlp.fc2 64 -> 49 us, attn.proj 28.5 -> 21.5 us against the full-row GEMM + LayerNorm kernels
-        // (also past 512 tiles of 128 x 128: at 48 k rows — the 4096^2 slab sweep — 1137 such tiles are 2.2 rounds of 512 slots,
-        // 758 tiles of 128 x 192 are 2.96 rounds of 256: sweep 557.7 -> 551.3 ms)
-        if (N % 192 == 0 && N / 192 <= 2 && M >= 4096)
-            return launch_gemm_dma<Cfg128x192, E, 3>(a, K, w, K, M, N, K, epi, s);
+        // Past 512 tiles of 128 x 128 the choice goes by how full the last round is: at 48 405 rows (the 4096^2 slab sweep) 1137
+        // tiles of 128 x 128 are 2.2 rounds of 512 slots, 758 of 128 x 192 are 2.96 rounds of 256 (sweep 557.7 -> 551.3 ms); at
+        // 50 176 rows (Swin-T stage 2) both shapes fill 77 % of their last round and the two-per-CU tile wins (183 against 215 us).
+        if (N % 192 == 0 && N / 192 <= 2 && M >= 4096) {
+            const long rb = (M + 127) / 128, t192 = rb * (N / 192), t128 = rb * ((N + 127) / 128);
+            const double e192 = (double)t192 / (256.0 * ((t192 + 255) / 256)), e128 = (double)t128 / (512.0 * ((t128 + 511) / 512));
+            if (t128 < 512 || e192 > 1.1 * e128) return launch_gemm_dma<Cfg128x192, E, 3>(a, K, w, K, M, N, K, epi, s);
+        }
         if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512) {
             // wide outputs (mlp.fc1): the same tile on eight wavefronts, four per SIMD with two workgroups per CU (58.0 -> 56.2 us
             // in the forward on one box, 53.0 -> 51.8 on another; the N = 384 layers lose on it: fc2 56 -> 62, proj 26 -> 27, and
