@@ -60,14 +60,14 @@ int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_t batch, fl
                      float *last_hidden, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Per-handle dispatch options. OCM_SWIN_OPT_FUSE_MLP (default 1): in split-bf16 precision the layers of the narrow stages
- * (96 or 128 channels) run their MLP half as ONE kernel (ocm_op_swin_mlp) and layernorm_before + the q | k | v projection
- * as one (ocm_op_swin_lnqkv); 0 runs LayerNorm kernels and GEMMs. Results agree to fp32 rounding. */
+ * (96 or 128 channels) run their MLP half as ONE kernel (ocm_op_swin_mlp), and those of up to 192 channels layernorm_before +
+ * the q | k | v projection as one (ocm_op_swin_lnqkv); 0 runs LayerNorm kernels and GEMMs. Results agree to fp32 rounding. */
 enum { OCM_SWIN_OPT_FUSE_MLP = 0 };
 int ocm_swin_set_option(ocm_swin_t *h, int32_t option, int32_t value);
 
 /* layernorm_before + the q | k | v projections of one SwinLayer (modeling_swin.py:641, :430-432) in one kernel:
  * qkv (tokens, 3 * channels) split pairs = LayerNorm(x; gamma, beta, eps) W^T + bias, W (3 * channels, channels) split pairs
- * (rows: q | k | v), x (tokens, channels) fp32. OCM_PREC_BF16X3, channels 96 or 128; anything else returns OCM_EINVAL. */
+ * (rows: q | k | v), x (tokens, channels) fp32. OCM_PREC_BF16X3, channels 96, 128 or 192; anything else returns OCM_EINVAL. */
 int ocm_op_swin_lnqkv(int32_t precision, const float *x, const float *gamma, const float *beta, const void *w,
                       const float *bias, void *qkv, int64_t tokens, int32_t channels, float eps, void *stream);
 

@@ -175,7 +175,7 @@ def test_swin_fused_mlp_op(lib, dev, T, Cn):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("T,Cn", [(3136, 96), (1000, 96), (33, 96), (700, 128)])
+@pytest.mark.parametrize("T,Cn", [(3136, 96), (1000, 96), (33, 96), (700, 128), (1500, 192)])
 def test_swin_fused_lnqkv_op(lib, dev, T, Cn):
     """ocm_op_swin_lnqkv (layernorm_before + the q | k | v projection in one kernel, split-bf16) against float64 torch
     (modeling_swin.py:641, :430-432); token counts with full, partial and single workgroups; rows past T stay untouched."""
@@ -197,7 +197,7 @@ def test_swin_fused_lnqkv_op(lib, dev, T, Cn):
     assert (qkv[T:] == -1).all()
     assert lib.ocm_op_swin_lnqkv(_lib.OCM_PREC_FP32, p(dv[0]), p(dv[1]), p(dv[2]), p(ws), p(dv[3]), p(qkv), T, Cn, 1e-5,
                                  st) == _lib.OCM_EINVAL
-    assert lib.ocm_op_swin_lnqkv(_lib.OCM_PREC_BF16X3, p(dv[0]), p(dv[1]), p(dv[2]), p(ws), p(dv[3]), p(qkv), T, 192, 1e-5,
+    assert lib.ocm_op_swin_lnqkv(_lib.OCM_PREC_BF16X3, p(dv[0]), p(dv[1]), p(dv[2]), p(ws), p(dv[3]), p(qkv), T, 384, 1e-5,
                                  st) == _lib.OCM_EINVAL
 
 

@@ -905,7 +905,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void swin_mlp_x3_kernel(f
 // HBM traffic: x once in, qkv once out (1.23 GB at 8e5 rows, against 0.6 + 1.23 GB for LayerNorm kernel + GEMM, the
 // latter at 2.9 TB/s on three-K-step tiles).
 template <int CG, int NW>
-__global__ __launch_bounds__(NW * 64, 4) void swin_lnqkv_x3_kernel(const float *__restrict__ x, const float *__restrict__ gam,
+__global__ __launch_bounds__(NW * 64, CG <= 4 ? 4 : 2) void swin_lnqkv_x3_kernel(const float *__restrict__ x, const float *__restrict__ gam,
                                                                   const float *__restrict__ bet, const char *__restrict__ w,
                                                                   const float *__restrict__ bias, char *__restrict__ qkv, int T,
                                                                   float eps) {
@@ -1023,7 +1023,8 @@ __global__ __launch_bounds__(NW * 64, 4) void swin_lnqkv_x3_kernel(const float *
 #undef OCM_QKV_DMA
 }
 
-bool swin_lnqkv_fused_supported(int prec, int C) { return prec == 2 && (C == 96 || C == 128); }
+// C = 192 (stage 1 of Swin-T: 96 registers of x fragments, a 72 KiB ring, two workgroups per CU) is the widest that fits
+bool swin_lnqkv_fused_supported(int prec, int C) { return prec == 2 && (C == 96 || C == 128 || C == 192); }
 
 hipError_t launch_swin_lnqkv(int prec, const float *x, const float *g, const float *be, const void *w, const float *bias,
                              void *qkv, size_t T, int C, float eps, hipStream_t s) {
@@ -1031,10 +1032,23 @@ hipError_t launch_swin_lnqkv(int prec, const float *x, const float *g, const flo
     constexpr int NW = 4;
     const dim3 grid((unsigned)((T + NW * 32 - 1) / (NW * 32))), block(NW * 64);
     const int lds = 3 * (C / 32 * 4096) + 3 * C * 4;
-    if (C == 96)
+    if (C == 96) {
         swin_lnqkv_x3_kernel<3, NW><<<grid, block, lds, s>>>(x, g, be, (const char *)w, bias, (char *)qkv, (int)T, eps);
-    else
+    } else if (C == 128) {
         swin_lnqkv_x3_kernel<4, NW><<<grid, block, lds, s>>>(x, g, be, (const char *)w, bias, (char *)qkv, (int)T, eps);
+    } else {
+        static unsigned long long optin = 0;
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+        if (!(optin >> (dev & 63) & 1)) {
+            if (hipError_t e = hipFuncSetAttribute((const void *)swin_lnqkv_x3_kernel<6, NW>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                e != hipSuccess)
+                return e;
+            optin |= 1ull << (dev & 63);
+        }
+        swin_lnqkv_x3_kernel<6, NW><<<grid, block, lds, s>>>(x, g, be, (const char *)w, bias, (char *)qkv, (int)T, eps);
+    }
     return hipGetLastError();
 }
 

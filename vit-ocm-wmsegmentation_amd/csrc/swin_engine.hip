@@ -362,7 +362,7 @@ extern "C" int ocm_op_swin_lnqkv(int32_t precision, const float *x, const float 
     if (pc < 0) return fail(OCM_EINVAL, "bad precision");
     if (tokens <= 0 || tokens > 0x7fffffffLL) return fail(OCM_EINVAL, "bad token count %lld", (long long)tokens);
     if (!swin_lnqkv_fused_supported(pc, channels))
-        return fail(OCM_EINVAL, "the fused LayerNorm + qkv projection is built for split-bf16 operands and 96 or 128 channels "
+        return fail(OCM_EINVAL, "the fused LayerNorm + qkv projection is built for split-bf16 operands and 96, 128 or 192 channels "
                                 "(got precision %d, %d channels)", precision, channels);
     HIP_TRY(launch_swin_lnqkv(pc, x, gamma, beta, w, bias, qkv, (size_t)tokens, channels, eps, (hipStream_t)stream));
     return OCM_OK;
