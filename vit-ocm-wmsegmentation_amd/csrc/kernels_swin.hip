@@ -904,12 +904,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 3) void swin_mlp_x3_kernel(f
 // accumulator registers (eight consecutive features per lane and run) leave as 16-byte pieces of the tokens' pair rows.
 // HBM traffic: x once in, qkv once out (1.23 GB at 8e5 rows, against 0.6 + 1.23 GB for LayerNorm kernel + GEMM, the
 // latter at 2.9 TB/s on three-K-step tiles).
-template <int CG, int NW>
+// (GELU: the same kernel as layernorm_after + SwinIntermediate — N = 4C output features, exact-erf GELU before the split — for
+// the stage whose MLP half does not fit swin_mlp_x3_kernel's registers: C = 192)
+template <int CG, int NW, bool GELU>
 __global__ __launch_bounds__(NW * 64, CG <= 4 ? 4 : 2) void swin_lnqkv_x3_kernel(const float *__restrict__ x, const float *__restrict__ gam,
                                                                   const float *__restrict__ bet, const char *__restrict__ w,
                                                                   const float *__restrict__ bias, char *__restrict__ qkv, int T,
-                                                                  float eps) {
-    constexpr int C = CG * 32, NF = 3 * CG, STAGE = CG * 4096, NSTAGE = 3, PIECES = 4 * CG, PPW = PIECES / NW, NS = 2 * CG;
+                                                                  int N, float eps) {
+    constexpr int C = CG * 32, STAGE = CG * 4096, NSTAGE = 3, PIECES = 4 * CG, PPW = PIECES / NW, NS = 2 * CG;
+    const int NF = N >> 5;  // chunks of 32 output features
     static_assert(PIECES % NW == 0, "the wavefronts share the pieces of a step evenly");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     float *bs = (float *)(smem + NSTAGE * STAGE);
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(NW * 64, CG <= 4 ? 4 : 2) void swin_lnqkv_x3_kernel
     const int tok0 = (blockIdx.x * NW + wave) * 32;
     const bool live = tok0 + r < T;
     const size_t tok = (size_t)min(tok0 + r, T - 1);
-    for (int i = tid; i < 3 * C; i += NW * 64) bs[i] = bias[i];
+    for (int i = tid; i < N; i += NW * 64) bs[i] = bias[i];
     int voff[PPW];
     {
         const int lrow = lane >> 3, slot = lane & 7;
@@ -931,7 +934,7 @@ __global__ __launch_bounds__(NW * 64, CG <= 4 ? 4 : 2) void swin_lnqkv_x3_kernel
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(3))) void *lds_ptr;
-    const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, (unsigned)(3 * C * C * 4), 0x00020000);
+    const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void *)w, 0, (unsigned)(N * C * 4), 0x00020000);
 #define OCM_QKV_DMA(j, st)                                                                                              \
     do {                                                                                                                \
         _Pragma("unroll") for (int jj = 0; jj < PPW; ++jj)                                                              \
@@ -942,7 +945,7 @@ __global__ __launch_bounds__(NW * 64, CG <= 4 ? 4 : 2) void swin_lnqkv_x3_kernel
 #define OCM_QKV_DMA(j, st) (void)0
 #endif
     OCM_QKV_DMA(0, 0);
-    OCM_QKV_DMA(1, 1);
+    if (NF > 1) OCM_QKV_DMA(1, 1);
     bf16x8 xh[NS], xl[NS];
     {
         const float *xr = x + tok * C + 8 * h;
@@ -976,7 +979,7 @@ __global__ __launch_bounds__(NW * 64, CG <= 4 ? 4 : 2) void swin_lnqkv_x3_kernel
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     const int pr = pi_row(r);
-    char *orow = qkv + tok * (3 * C * 4);
+    char *orow = qkv + tok * ((size_t)N * 4);
     int sc = 0, si = 2;
     for (int j = 0; j < NF; ++j) {
         if (j + 1 < NF)
@@ -1009,10 +1012,18 @@ __global__ __launch_bounds__(NW * 64, CG <= 4 ? 4 : 2) void swin_lnqkv_x3_kernel
                 u0[e] = S[8 * s2 + e] + c0[e];
                 u1[e] = S[8 * s2 + 4 + e] + c1[e];
             }
+            if (GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const f32x2 a = gelu_erf2(f32x2{u0[e], u0[e + 1]}), b = gelu_erf2(f32x2{u1[e], u1[e + 1]});
+                    u0[e] = a[0]; u0[e + 1] = a[1];
+                    u1[e] = b[0]; u1[e + 1] = b[1];
+                }
+            }
             bf16x8 ph, pl;
             split8(u0, u1, ph, pl);
             if (live) {
-                char *p = orow + j * 128 + (16 * s2 + 8 * h) * 2;
+                char *p = orow + (size_t)j * 128 + (16 * s2 + 8 * h) * 2;
                 *(bf16x8 *)p = ph;
                 *(bf16x8 *)(p + 64) = pl;
             }
@@ -1026,30 +1037,45 @@ __global__ __launch_bounds__(NW * 64, CG <= 4 ? 4 : 2) void swin_lnqkv_x3_kernel
 // C = 192 (stage 1 of Swin-T: 96 registers of x fragments, a 72 KiB ring, two workgroups per CU) is the widest that fits
 bool swin_lnqkv_fused_supported(int prec, int C) { return prec == 2 && (C == 96 || C == 128 || C == 192); }
 
-hipError_t launch_swin_lnqkv(int prec, const float *x, const float *g, const float *be, const void *w, const float *bias,
-                             void *qkv, size_t T, int C, float eps, hipStream_t s) {
-    if (!swin_lnqkv_fused_supported(prec, C) || T == 0 || T > 0x7fffffffu) return hipErrorInvalidValue;
+// LayerNorm(x) W^T + b [-> GELU] as split pairs, W (N, C): the q | k | v projection (N = 3C) or SwinIntermediate (N = 4C, gelu)
+hipError_t launch_swin_lnlinear(int prec, const float *x, const float *g, const float *be, const void *w, const float *bias,
+                                void *out, size_t T, int C, int N, bool gelu, float eps, hipStream_t s) {
+    if (!swin_lnqkv_fused_supported(prec, C) || T == 0 || T > 0x7fffffffu || N <= 0 || N % 32 || N > 4096) return hipErrorInvalidValue;
     constexpr int NW = 4;
     const dim3 grid((unsigned)((T + NW * 32 - 1) / (NW * 32))), block(NW * 64);
-    const int lds = 3 * (C / 32 * 4096) + 3 * C * 4;
+    const int lds = 3 * (C / 32 * 4096) + N * 4;
+    const void *kern = nullptr;
+#define OCM_LNL(CG_, G_)                                                                                                \
+    do {                                                                                                                \
+        kern = (const void *)swin_lnqkv_x3_kernel<CG_, NW, G_>;                                                         \
+        if (lds > 64 * 1024) {                                                                                          \
+            static unsigned long long optin = 0;                                                                        \
+            int dev = 0;                                                                                                \
+            if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;                                           \
+            if (!(optin >> (dev & 63) & 1)) {                                                                           \
+                if (hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);    \
+                    e != hipSuccess)                                                                                    \
+                    return e;                                                                                           \
+                optin |= 1ull << (dev & 63);                                                                            \
+            }                                                                                                           \
+        }                                                                                                               \
+        swin_lnqkv_x3_kernel<CG_, NW, G_><<<grid, block, lds, s>>>(x, g, be, (const char *)w, bias, (char *)out, (int)T, N, \
+                                                                   eps);                                                \
+    } while (0)
     if (C == 96) {
-        swin_lnqkv_x3_kernel<3, NW><<<grid, block, lds, s>>>(x, g, be, (const char *)w, bias, (char *)qkv, (int)T, eps);
+        if (gelu) OCM_LNL(3, true); else OCM_LNL(3, false);
     } else if (C == 128) {
-        swin_lnqkv_x3_kernel<4, NW><<<grid, block, lds, s>>>(x, g, be, (const char *)w, bias, (char *)qkv, (int)T, eps);
+        if (gelu) OCM_LNL(4, true); else OCM_LNL(4, false);
     } else {
-        static unsigned long long optin = 0;
-        int dev = 0;
-        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-        if (!(optin >> (dev & 63) & 1)) {
-            if (hipError_t e = hipFuncSetAttribute((const void *)swin_lnqkv_x3_kernel<6, NW>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                e != hipSuccess)
-                return e;
-            optin |= 1ull << (dev & 63);
-        }
-        swin_lnqkv_x3_kernel<6, NW><<<grid, block, lds, s>>>(x, g, be, (const char *)w, bias, (char *)qkv, (int)T, eps);
+        if (gelu) OCM_LNL(6, true); else OCM_LNL(6, false);
     }
+#undef OCM_LNL
     return hipGetLastError();
+}
+
+hipError_t launch_swin_lnqkv(int prec, const float *x, const float *g, const float *be, const void *w, const float *bias,
+                             void *qkv, size_t T, int C, float eps, hipStream_t s) {
+    return launch_swin_lnlinear(prec, x, g, be, w, bias, qkv, T, C, 3 * C, false, eps, s);
 }
 
 bool swin_mlp_fused_supported(int prec, int C, int hidden) { return prec == 2 && hidden == 4 * C && (C == 96 || C == 128); }

@@ -145,6 +145,9 @@ hipError_t launch_swin_window_attention(int prec, const void *qkv, int ld, void 
 bool swin_lnqkv_fused_supported(int prec, int C);
 hipError_t launch_swin_lnqkv(int prec, const float *x, const float *g, const float *be, const void *w, const float *bias,
                              void *qkv, size_t T, int C, float eps, hipStream_t s);
+// the same kernel for any N (multiple of 32) output features, optionally with the exact-erf GELU: layernorm_after + mlp.fc1
+hipError_t launch_swin_lnlinear(int prec, const float *x, const float *g, const float *be, const void *w, const float *bias,
+                                void *out, size_t T, int C, int N, bool gelu, float eps, hipStream_t s);
 // SwinLayer's MLP half in one kernel (split-bf16, C = 96 / 128, hidden = 4 C): x += fc2(gelu(fc1(LayerNorm(x))))
 bool swin_mlp_fused_supported(int prec, int C, int hidden);
 hipError_t launch_swin_mlp(int prec, float *x, const float *g, const float *be, const void *w1, const float *b1,

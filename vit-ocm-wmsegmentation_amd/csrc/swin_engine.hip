@@ -319,10 +319,15 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
                                         h->ptr<float>(lp.b1), h->ptr<char>(lp.w2), h->ptr<float>(lp.b2), T, C, M, eps, s));
                 continue;
             }
-            HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln2_g), h->ptr<float>(lp.ln2_b), w.xn, T, C, Kc, eps,
-                                   false, 0, 0, s));
-            HIP_TRY(swin_linear(pc, w.xn, Kc, h->ptr<char>(lp.w1), h->ptr<float>(lp.b1), nullptr, w.hid, Km, (int)T, M,
-                                     Kc, OCM_EPI_BIAS_GELU_BF16, s));
+            if (h->fuse_mlp && swin_lnqkv_fused_supported(pc, C)) {  // C = 192: layernorm_after + fc1 + GELU in one kernel
+                HIP_TRY(launch_swin_lnlinear(pc, x, h->ptr<float>(lp.ln2_g), h->ptr<float>(lp.ln2_b), h->ptr<char>(lp.w1),
+                                             h->ptr<float>(lp.b1), w.hid, T, C, M, true, eps, s));
+            } else {
+                HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln2_g), h->ptr<float>(lp.ln2_b), w.xn, T, C, Kc, eps,
+                                       false, 0, 0, s));
+                HIP_TRY(swin_linear(pc, w.xn, Kc, h->ptr<char>(lp.w1), h->ptr<float>(lp.b1), nullptr, w.hid, Km, (int)T, M,
+                                         Kc, OCM_EPI_BIAS_GELU_BF16, s));
+            }
             HIP_TRY(swin_linear(pc, w.hid, Km, h->ptr<char>(lp.w2), h->ptr<float>(lp.b2), x, x, C, (int)T, C, Km,
                                      OCM_EPI_BIAS_RESID_F32, s));
         }
