@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Development tool (GPU box; `make -C vit-ocm-wmsegmentation_amd/csrc stamps`): phase stamps of the LDS-DMA nn.Linear kernels at the
+row counts of a one-tile-per-call forward (M = 197): cycles until the first tile lands, per K step (own-DMA wait, barrier),
+epilogue. DESIGN.md section 3.11 quotes its output for the four-wave tile (850 cycles per K step for 384 cycles of MFMA).
+    python tools/stamps_b1.py"""
 import ctypes as C, os, sys
 ROOT = os.getcwd()
 sys.path.insert(0, ROOT)
