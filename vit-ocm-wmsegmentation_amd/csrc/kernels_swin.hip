@@ -468,10 +468,26 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
     }
 }
 
+// Eight consecutive rows of one column of a row-major 16-bit LDS tile as an MFMA fragment: two ds_read_b64_tr_b16 (gfx950),
+// the second four rows (256 bytes at 64-byte rows) further down. `p` is this lane's address for the first block.
+__device__ __forceinline__ bf16x8 tr_read8(const char *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * 64));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+#else
+    return bf16x8{};
+#endif
+}
+
 // split-bf16 (OCM_PREC_BF16X3): swin_wattn_kernel on [hi | lo] pairs. One head of one token is exactly one 128-byte
 // group of the operand row (head_dim 32: 32 x hi | 32 x lo), so q / k / v fragments are 16-byte pieces of it; scores and
 // context are three MFMAs per product (mfma32x3), the probabilities are split in registers, the context leaves as pairs.
-// LDS per wavefront: K 64 keys x 128 B (hi | lo), V^T 32 dims x (64 keys hi + 64 keys lo) = two [32][128 B] images.
+// LDS per wavefront: K 64 keys x 128 B (hi | lo), V as two row-major [64 keys][64 B] images (hi, lo) read transposed.
 constexpr int WATTN_X3_WAVES = 3;  // 16.1 KiB of LDS per wavefront: three workgroups of three per CU
 template <int WS>
 __global__ __launch_bounds__(WATTN_X3_WAVES * 64) void swin_wattn_x3_kernel(const char *__restrict__ qkv, int ld, char *__restrict__ ctx,
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(WATTN_X3_WAVES * 64) void swin_wattn_x3_kernel(cons
     const int id = blockIdx.x * WATTN_X3_WAVES + wave;
     if (id >= total) return;  // no workgroup barrier below: every wave owns its LDS slice
     char *Ks = smem + wave * PER_WAVE;  // K: 64 keys x 128 B, chunks 0..3 = hi, 4..7 = lo (lds_off swizzle)
-    char *Vh = Ks + 64 * 128;           // V^T hi: 32 dims x 64 keys; V^T lo follows
+    char *Vh = Ks + 64 * 128;           // V hi: [64 keys][32 dims] row-major (64-byte rows); V lo follows
     char *Vl = Vh + 32 * 128;
     unsigned char *Rg = (unsigned char *)(Vl + 32 * 128);
     const int head = id % g.heads, wlin = (id / g.heads) % g.nW, b = id / (g.heads * g.nW);
@@ -523,12 +539,9 @@ __global__ __launch_bounds__(WATTN_X3_WAVES * 64) void swin_wattn_x3_kernel(cons
     for (int i = 0; i < 8; ++i) {
         const int idx = lane + 64 * i, key = idx >> 3, ch = idx & 7;
         *(bf16x8 *)(Ks + lds_off(key, ch)) = kreg[i];
-        char *vt = ch < 4 ? Vh : Vl;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int d = (ch & 3) * 8 + e;
-            *(bf16 *)(vt + lds_off(d, key >> 3) + (key & 7) * 2) = vreg[i][e];
-        }
+        // V stays row-major ([64 keys][32 dims] per half, 64-byte rows): the context product reads it TRANSPOSED from LDS
+        // (ds_read_b64_tr_b16 below) instead of scattering sixteen-bit elements into a V^T image here
+        *(bf16x8 *)((ch < 4 ? Vh : Vl) + key * 64 + (ch & 3) * 16) = vreg[i];
     }
     const bool masked = g.shift > 0 && (wy == g.H / ws - 1 || wx == g.nWx - 1);  // wave-uniform
     if (masked) Rg[lane] = (unsigned char)(lane < A ? win_region(g, ws, wy, wx, lane) : 0);
@@ -598,8 +611,11 @@ __global__ __launch_bounds__(WATTN_X3_WAVES * 64) void swin_wattn_x3_kernel(cons
                     ph[e] = t;
                     pl[e] = (bf16)(pv - (float)t);
                 }
-                const bf16x8 vh = *(const bf16x8 *)(Vh + lds_off(r, 4 * sub + 2 * s2 + h));
-                const bf16x8 vl = *(const bf16x8 *)(Vl + lds_off(r, 4 * sub + 2 * s2 + h));
+                // A operand V^T[d = lane & 31][8 keys from sub * 32 + 16 s2 + 8 h]: two transposed reads of 4 keys x 16 dims
+                // per 16-lane group (lane 4 q + p of a group addresses key row q, dims 4 p .. 4 p + 3 of the block; lane i
+                // receives dim i of the four keys). Every lane is active here (whole wavefronts leave the kernel together).
+                const int voff = (sub * 32 + 16 * s2 + 8 * h + ((lane >> 2) & 3)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+                const bf16x8 vh = tr_read8(Vh + voff), vl = tr_read8(Vl + voff);
                 O = mfma32x3(vh, vl, ph, pl, O);
             }
         // Lane (r, h) holds dims {8g + 4h + e} in fp32: the pair halves go out as four 8-byte pieces per half
