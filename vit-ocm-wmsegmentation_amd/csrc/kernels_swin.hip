@@ -315,6 +315,22 @@ __device__ __forceinline__ int win_region(const WinGeom &g, int ws, int wy, int 
     return ry * 3 + rx;
 }
 
+// Eight consecutive rows of one column of a row-major 16-bit LDS tile as an MFMA fragment: two ds_read_b64_tr_b16 (gfx950),
+// the second four rows (256 bytes at 64-byte rows) further down. `p` is this lane's address for the first block.
+__device__ __forceinline__ bf16x8 tr_read8(const char *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * 64));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+#else
+    return bf16x8{};
+#endif
+}
+
 // bf16 / MFMA: one wavefront per (b, window, head), head_dim 32, ws*ws <= 64 positions.
 // S^T = K.Q^T with the K rows in pi order (common.h): registers hold keys, the lane holds the query, so the
 // row max / sum are in-register reductions plus one lane <-> lane+32 exchange and the exponentiated tile is
@@ -329,7 +345,7 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
     const int id = blockIdx.x * 4 + wave;
     if (id >= total) return;  // no workgroup barrier below: every wave owns its LDS slice
     char *Ks = smem + wave * (64 * 64 + 32 * 128 + 64);  // K: 64 keys x 64 B
-    char *Vs = Ks + 64 * 64;                             // V^T: 32 dims x 128 B (lds_off swizzle)
+    char *Vs = Ks + 64 * 64;                             // V: [64 keys][32 dims] row-major, 64-byte rows (read transposed)
     unsigned char *Rg = (unsigned char *)(Vs + 32 * 128);
     const int head = id % g.heads, wlin = (id / g.heads) % g.nW, b = id / (g.heads * g.nW);
     const int wy = wlin / g.nWx, wx = wlin - wy * g.nWx;
@@ -362,11 +378,7 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
     for (int i = 0; i < 4; ++i) {
         const int idx = lane + 64 * i, key = idx >> 2, ch = idx & 3;
         *(bf16x8 *)(Ks + key * 64 + ((ch ^ ((key >> 2) & 3)) << 4)) = kreg[i];  // chunk swizzle: conflict-free b128 reads
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int d = ch * 8 + e;
-            *(bf16 *)(Vs + lds_off(d, key >> 3) + (key & 7) * 2) = vreg[i][e];
-        }
+        *(bf16x8 *)(Vs + key * 64 + ch * 16) = vreg[i];  // V row-major [64 keys][32 dims]: read transposed below (tr_read8)
     }
     const bool masked = g.shift > 0 && (wy == g.H / ws - 1 || wx == g.nWx - 1);  // wave-uniform
     if (masked) Rg[lane] = (unsigned char)(lane < A ? win_region(g, ws, wy, wx, lane) : 0);
@@ -430,7 +442,8 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
                 bf16x8 pb;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pb[e] = (bf16)S[sub][8 * s2 + e];
-                const bf16x8 a = *(const bf16x8 *)(Vs + lds_off(r, 4 * sub + 2 * s2 + h));
+                const bf16x8 a = tr_read8(Vs + (sub * 32 + 16 * s2 + 8 * h + ((lane >> 2) & 3)) * 64 +
+                                          (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2);
                 O = mfma32(a, pb, O);
             }
         // Lane (r, h) holds dims {8g + 4h + e}: trade half of them with lane (r, h ^ 1) so that each lane owns 16
@@ -466,22 +479,6 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
             }
         }
     }
-}
-
-// Eight consecutive rows of one column of a row-major 16-bit LDS tile as an MFMA fragment: two ds_read_b64_tr_b16 (gfx950),
-// the second four rows (256 bytes at 64-byte rows) further down. `p` is this lane's address for the first block.
-__device__ __forceinline__ bf16x8 tr_read8(const char *p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef short s16x4 __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) s16x4 *lds_s16x4;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p);
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 4 * 64));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    return __builtin_bit_cast(bf16x8, v);
-#else
-    return bf16x8{};
-#endif
 }
 
 // split-bf16 (OCM_PREC_BF16X3): swin_wattn_kernel on [hi | lo] pairs. One head of one token is exactly one 128-byte
