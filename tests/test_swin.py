@@ -47,6 +47,10 @@ def test_mirror_keeps_transformers_state_dict_keys():
     assert cfg.hidden_size == 768 and m.num_labels == 5
     with pytest.raises(RuntimeError, match="HIP"):
         m(pixel_values=torch.zeros(1, 3, 224, 224))
+    for mode in ("bf16", "fp32", "bf16x3"):  # the split-bf16 mode exists for Swin since round 3
+        assert m.set_precision(mode) is m
+    with pytest.raises(ValueError):
+        m.set_precision("fp16")
 
 
 def test_swin_create_rejects_unbuilt_geometries(lib):
