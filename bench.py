@@ -101,6 +101,12 @@ def cpu_baseline(arch_dims, patch, size, batch, seconds_budget=20.0):
                       f"callers run B = 1)"}
 
 
+def spread(values):
+    """[min, median, max] of the per-rank figures, 3 decimals."""
+    v = sorted(values)
+    return [round(v[0], 3), round(v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2]), 3), round(v[-1], 3)]
+
+
 def slab_sweep(args, dev, world, rank, lib):
     """BASELINE.json configs[3] — the path north_star prices at 8 GPUs: ViT-S/8 sliding-window sweep of a 4096^2 slab
     (900 windows of 384^2, N = 2305) sharded over the ranks with one all-gather of the CLS-row maps. STRONG scaling:
@@ -128,10 +134,17 @@ def slab_sweep(args, dev, world, rank, lib):
         maps = sweep(slab)
     sync()
     dt = (time.perf_counter() - t0) / reps
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    # every rank's own figures travel to rank 0: its sweep time, its share of the windows and how many forwards its plan has
+    # (an imbalance — 113 / 109 windows, auto plans of different length — must be visible next to the max-over-ranks time)
+    from vit_ocm_wmsegmentation_amd.sw_processing import shard_range
+    b_own, e_own, _ = shard_range(maps.shape[0], world, rank)
+    own_plan = sweep._plan(e_own - b_own, 2305, dev)
+    mine = torch.tensor([dt, e_own - b_own, len(own_plan)], dtype=torch.float64, device=dev)
+    per_rank = [mine.clone() for _ in range(world)]
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.all_gather(per_rank, mine)
+    per_rank = [[float(v) for v in t.tolist()] for t in per_rank]
+    dt = max(r[0] for r in per_rank)
     # dominant kernel of a rank's share, timed with HIP events on the launch stream. The sweep ends in a collective, so
     # EVERY rank runs this extra pass (each profiles its own launches); rank 0 reports its figures.
     roof = None
@@ -143,9 +156,7 @@ def slab_sweep(args, dev, world, rank, lib):
     _lib.check(lib.ocm_prof_end(ms, cnt))
     if rank == 0:
         D, Hh, N = 384, 6, 2305
-        from vit_ocm_wmsegmentation_amd.sw_processing import shard_range
-        b0, e0, _ = shard_range(maps.shape[0], world, rank)
-        plan = sweep._plan(e0 - b0, N, dev)  # windows per forward on this rank (auto: whole rounds of the CUs)
+        b0, e0, plan = b_own, e_own, own_plan  # windows per forward on this rank (auto: whole rounds of the CUs)
         cf1 = class_flops(D, 4 * D, N, 1, 8, 3)
         cf = {c: v * (e0 - b0) / len(plan) for c, v in cf1.items()}  # mean FLOPs per launch
         dom = max((c for c in _lib.KERNEL_CLASSES if c in cf), key=lambda c: ms[_lib.KERNEL_CLASSES.index(c)])
@@ -169,6 +180,8 @@ def slab_sweep(args, dev, world, rank, lib):
     return {"workload": f"vit_small patch 8, {args.slab_size}^2 slab -> {T} windows of 384^2 (N=2305), up to 24 windows per forward (auto), "
                         f"CLS-row maps, tile shard x{world} + one all-gather", "scaling": "strong", "n_gpus": world,
             "windows": T, "ms_per_sweep": round(dt * 1e3, 2), "value": round(T / dt, 1), "unit": "windows/s",
+            "per_rank_ms": spread([r[0] * 1e3 for r in per_rank]), "windows_per_rank": [int(r[1]) for r in per_rank],
+            "forwards_per_rank": [int(r[2]) for r in per_rank],
             "path_tflops": round(T / dt * fwin / 1e12, 2), "roofline": roof}
 
 
@@ -294,10 +307,11 @@ def main():
     _lib.check(lib.ocm_prof_end(ms, cnt))
     dom_ms, dom_n = ms[dom_idx], cnt[dom_idx]
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tall = [torch.tensor([dt], dtype=torch.float64, device=dev) for _ in range(world)]
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.all_gather(tall, tall[rank].clone())
+    rank_ms = [float(t.item()) / args.steps * 1e3 for t in tall]  # ms per step as each rank saw it
+    dt = max(float(t.item()) for t in tall)                       # the contract: MAX over ranks
 
     # per-class breakdown (separate, untimed pass: events around every launch)
     breakdown = None
@@ -330,10 +344,21 @@ def main():
         slab = slab_sweep(args, dev, world, rank, lib)
         out = model._run(x, flags=flags)
 
+    # Everything collective is done. The other ranks leave the process group NOW, so that what follows on rank 0 — the parity
+    # probe and the CPU baseline, which claims the host's cores — runs with nobody parked in an RCCL barrier beside it.
+    comm = {"backend": backend, "visible_devices": ndev, "world": world}
+    if world > 1:
+        if backend == "nccl":
+            try:
+                comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as exc:  # noqa: BLE001 - version query only
+                comm["rccl_version"] = f"unavailable ({type(exc).__name__})"
+        names = [None] * world
+        dist.all_gather_object(names, f"{torch.cuda.get_device_name(dev)} #{torch.cuda.current_device()} pid {os.getpid()}")
+        comm["ranks"] = names
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
         return
 
     # parity of what was just timed: attention-map L_inf vs the CPU oracle on the FIRST, MIDDLE and LAST tile of the bench
@@ -411,6 +436,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "per_rank_ms": spread(rank_ms),
+        "comm": comm,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -438,9 +465,6 @@ def main():
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline((D, L, H), p, S, B)
     print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

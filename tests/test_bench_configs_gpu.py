@@ -107,3 +107,34 @@ def test_misaligned_slab_view_is_copied(dev):
     assert view.stride(2) == 1 and view.data_ptr() % 16 != 0
     sweep = SlidingWindowAttention(case_model, window=224, stride=64, batch_tiles=4)
     assert torch.equal(sweep(view), sweep(tile))
+
+
+@pytest.mark.parametrize("precision,tol", [("bf16x3", 1e-3), ("fp32", 2e-4)])
+def test_config5_swin_batch256_sampled_images(dev, precision, tol):
+    """BASELINE config 5 at ITS batch: Swin-T 224^2, 256 images (Allen_data_Backbone/train.py:70-85). At B = 256 the stages
+    dispatch other kernels than the B = 2 / 3 fixtures (802 816 .. 12 544 token rows: 128 x 192 / 256 x 256 / eight-wave
+    128 x 128 LDS-DMA tiles instead of the small-row paths; profiles/r03_kernel_stats_swin.csv), so the first, middle and
+    last image are compared with the transformers-pinned oracle run on the same synthetic weights: logits and pooled output
+    at the ViT path's 1e-3 in the default split-bf16 arithmetic, 2e-4 in fp32 mode."""
+    from oracle import swin_oracle as SO
+    from vit_ocm_wmsegmentation_amd import swin as SW
+    cfg = dict(synth.SWIN_TINY)
+    sd = synth.synth_swin_state_dict(cfg, seed=21, qk_gain=6.0)
+    x = synth.synth_tiles(256, 224, seed=71)
+    model = SW.SwinForImageClassification(SW.SwinConfig(num_labels=cfg["num_labels"]))
+    assert not model.load_state_dict(sd, strict=True).missing_keys
+    model = model.to(dev).eval().set_precision(precision)
+    out = model(pixel_values=x.to(dev), output_hidden_states=True)
+    assert tuple(out.logits.shape) == (256, cfg["num_labels"])
+    pick = [0, 127, 255]
+    want = SO.swin_forward(sd, cfg, x[pick])
+    e_log = float((out.logits[pick].cpu() - want["logits"]).abs().max())
+    e_pool = float((out.pooler_output[pick].cpu() - want["pooled"]).abs().max())
+    e_hid = float((out.last_hidden_state[pick].cpu() - want["last_hidden_state"]).abs().max())
+    print(f"\n[config 5, {precision}] Swin-T B=256 images {pick}: logits {e_log:.2e}, pooled {e_pool:.2e}, last hidden {e_hid:.2e}")
+    assert e_log <= tol and e_pool <= tol and e_hid <= 4 * tol
+    assert torch.equal(out.logits[pick].argmax(-1).cpu(), want["logits"].argmax(-1))
+    # the same three images as a batch of three (the small-row dispatch) agree with their rows of the big batch
+    small = model(pixel_values=x[pick].to(dev))
+    assert float((small.logits - out.logits[pick]).abs().max()) <= tol
+    assert torch.isfinite(out.logits).all()

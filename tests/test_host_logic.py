@@ -26,6 +26,16 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"libocm_vit.so does not export {name}"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert lib.ocm_abi_version() == _lib.OCM_ABI_VERSION
+    # ... and nothing BUT the C ABI: no mangled launcher, kernel host stub or global leaks into the dynamic symbol table
+    # (csrc/exports.map; development-only ocm_debug_* entry points exist in `make dev` builds, never in the shipped library)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert exported, "nm found no dynamic symbols"
+    stray = sorted(n for n in exported if not n.startswith("ocm_"))
+    assert not stray, f"non-ABI symbols exported: {stray[:5]} (+{max(0, len(stray) - 5)})"
+    assert not [n for n in exported if n.startswith("ocm_debug")], "development entry points in the shipped library"
+    assert declared <= exported
 
 
 def test_create_rejects_bad_configs(lib):
@@ -219,6 +229,17 @@ def test_engine_parameter_slots_follow_replaced_parameters():
     import pickle
     m2 = pickle.loads(pickle.dumps(m))  # the cached slots hold module references: they are not part of the pickled state
     assert set(dict(m2._named_engine_params())) == want
+    # a replaced SUB-MODULE is followed too (the cache used to keep reading the old module's parameters)
+    new_qkv = nn.Linear(192, 576)
+    m.blocks[2].attn.qkv = new_qkv
+    again = dict(m._named_engine_params())
+    assert again["blocks.2.attn.qkv.weight"] is new_qkv.weight and again["blocks.2.attn.qkv.bias"] is new_qkv.bias
+    blk = vits.Block(192, 3, qkv_bias=True)
+    m.blocks[3] = blk
+    assert dict(m._named_engine_params())["blocks.3.mlp.fc2.weight"] is blk.mlp.fc2.weight
+    m.blocks[0].attn.proj.bias = None  # a parameter removed after caching drops out instead of raising
+    assert "blocks.0.attn.proj.bias" not in dict(m._named_engine_params())
+    assert set(dict(m._named_engine_params())) == want - {"blocks.0.attn.proj.bias"}
 
 
 def test_stress_variant_is_calibrated_per_geometry():

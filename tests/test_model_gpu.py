@@ -309,11 +309,17 @@ def test_folded_layernorm_matches_layernorm_kernels(dev, name):
     f1b, a1b, q1b = model.get_intermediate_feat(x, 2)
     for u, v in zip(f1 + a1 + q1, f1b + a1b + q1b):
         assert torch.equal(u, v)
+    # the third call would replay the capture of the folded launch sequence if the replay key ignored the option
+    # (ADVICE r3): the setters bump Engine.option_epoch, which is part of the key — and the two paths must differ in
+    # at least one bit, or this test compares folded against folded
+    n_graphs = len(model.__dict__.get("_auto_graphs", {}))
     try:
         eng.set_fold_layernorm(False)
         f0, a0, q0 = model.get_intermediate_feat(x, 2)
+        assert len(model.__dict__.get("_auto_graphs", {})) == n_graphs  # first sighting of the new key: launch by launch
     finally:
         eng.set_fold_layernorm(True)
+    assert sum(int((u != v).sum()) for u, v in zip(f0 + a0 + q0, f1 + a1 + q1)) > 0, "LayerNorm kernels and the fold gave the same bits"
     tol = 5e-4 if name in STRESS else 1e-6
     for u, v in zip(a0, a1):
         assert float((u - v).abs().max()) <= tol

@@ -143,8 +143,8 @@ def test_auto_batch_plan_is_balanced_bounded_and_avoids_spilled_rounds():
     assert sum(p) == 900 and max(p) <= 24 and max(p) - min(p) <= 1
     # 21 windows = 379 row tiles x 12 column tiles of mlp.fc1 = 8.9 rounds of 512 slots; 22 would spill into a tenth
     assert max(p) == 21 and len(p) == 43
-    # forwards on the fused 64-row kernels pay for whole rounds of the CUs: 9 windows of 2305 tokens are 325 row
-    # tiles (two rounds) in one forward and cost no less split up -> the fewest forwards
+    # a forward of 9 windows (20 745 rows: mlp.fc2 on 128 x 192 tiles, one per CU; mlp.fc1 on 128 x 128, two per CU) pays for
+    # whole rounds of either grid and costs no less split up -> the fewest forwards
     assert auto(9, 2305, 256) == [9]
     assert auto(30, 197, 256) == [15, 15]   # short sequences: one round whatever the size -> the fewest forwards
     assert auto(5, 2305, 256, max_batch=24) == [5] and auto(0, 2305, 256) == []

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -28,8 +30,15 @@ int ocm_fail(int code, const char *fmt, ...) {
 // ------------------------------------------------------------------------------------------
 // kernel-class timing with hipEvents (diagnostic)
 // ------------------------------------------------------------------------------------------
+// One process-wide session (ocm_prof_begin .. ocm_prof_end). The state is shared by every handle and every host thread that
+// launches through this library, so it is guarded: `on` is an atomic that launch paths read without the lock while no session
+// is open (the common case: one relaxed load per launch); claiming a slot, recording into it and tearing the session down take
+// the mutex, and a scope that outlives its session (ocm_prof_end on another thread between its two records) sees a new
+// generation and records nothing.
 struct Prof {
-    bool on = false;
+    std::atomic<bool> on{false};
+    std::mutex mu;
+    uint64_t gen = 0;
     uint32_t mask = 0;
     std::vector<hipEvent_t> ev;  // pairs
     std::vector<int> cls;
@@ -40,34 +49,43 @@ static Prof g_prof;
 struct ProfScope {
     hipStream_t s;
     int idx = -1;
+    uint64_t gen = 0;
     ProfScope(int kclass, hipStream_t stream) : s(stream) {
-        if (g_prof.on && (g_prof.mask >> kclass & 1) && g_prof.used * 2 + 1 < g_prof.ev.size()) {
+        if (!g_prof.on.load(std::memory_order_acquire)) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (g_prof.on.load(std::memory_order_relaxed) && (g_prof.mask >> kclass & 1) && g_prof.used * 2 + 1 < g_prof.ev.size()) {
             idx = (int)g_prof.used++;
+            gen = g_prof.gen;
             g_prof.cls[idx] = kclass;
             (void)hipEventRecord(g_prof.ev[2 * idx], s);
         }
     }
     ~ProfScope() {
-        if (idx >= 0) (void)hipEventRecord(g_prof.ev[2 * idx + 1], s);
+        if (idx < 0) return;
+        std::lock_guard<std::mutex> lk(g_prof.mu);
+        if (g_prof.on.load(std::memory_order_relaxed) && g_prof.gen == gen) (void)hipEventRecord(g_prof.ev[2 * idx + 1], s);
     }
 };
 #define PROF(kclass, stream) ProfScope prof_scope_##__LINE__(kclass, stream)
 
 extern "C" int ocm_prof_begin(uint32_t class_mask, int32_t max_launches) {
-    if (g_prof.on) return fail(OCM_ESTATE, "profiling already active");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (g_prof.on.load(std::memory_order_relaxed)) return fail(OCM_ESTATE, "profiling already active");
     if (max_launches <= 0) return fail(OCM_EINVAL, "max_launches must be positive");
     g_prof.ev.resize((size_t)max_launches * 2);
     g_prof.cls.assign(max_launches, 0);
     for (auto &e : g_prof.ev) HIP_TRY(hipEventCreate(&e));
     g_prof.used = 0;
     g_prof.mask = class_mask;
-    g_prof.on = true;
+    ++g_prof.gen;
+    g_prof.on.store(true, std::memory_order_release);
     return OCM_OK;
 }
 
 extern "C" int ocm_prof_end(double *ms_per_class, int64_t *launches_per_class) {
-    if (!g_prof.on) return fail(OCM_ESTATE, "profiling is not active");
-    g_prof.on = false;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (!g_prof.on.load(std::memory_order_relaxed)) return fail(OCM_ESTATE, "profiling is not active");
+    g_prof.on.store(false, std::memory_order_release);
     for (int c = 0; c < OCM_K_COUNT; ++c) {
         if (ms_per_class) ms_per_class[c] = 0.0;
         if (launches_per_class) launches_per_class[c] = 0;

@@ -14,6 +14,8 @@ No forward below calls their ATen kernels; every method packs device pointers an
 (the CPU statement of this arithmetic is the test oracle under oracle/).
 """
 import math
+import threading
+import warnings
 from functools import partial
 
 import torch
@@ -256,6 +258,7 @@ class VisionTransformer(nn.Module):
         st.pop("_auto_graphs", None)
         st.pop("_param_slots", None)
         st.pop("_auto_seen", None)
+        st.pop("_auto_lock", None)  # locks do not pickle / deepcopy
         return st
 
     # ---- engine management ------------------------------------------------------------------
@@ -293,9 +296,14 @@ class VisionTransformer(nn.Module):
     def _named_engine_params(self):
         """(name, parameter) of everything the engine holds a copy of. The (owning module, key) pairs are resolved once —
         walking the module tree with named_parameters() costs more than a one-tile forward's launches — and the parameters
-        are then read from the modules' own dicts, so a replaced Parameter object is still seen."""
-        slots = self.__dict__.get("_param_slots")
-        if slots is None:
+        are then read from the modules' own dicts, so a replaced Parameter object is still seen. A replaced SUB-MODULE
+        (`blk.attn.qkv = nn.Linear(...)`, a swapped Block, a LoRA / quantisation wrapper) is seen too: the cache keeps the
+        (parent._modules, child name, child) edges of the tree it was built from and is rebuilt when one of them no longer
+        holds (174 identity checks for ViT-S, ~10 us). A parameter set to None afterwards (`lin.bias = None`) drops out."""
+        cached = self.__dict__.get("_param_slots")
+        if cached is not None and not all(d.get(n) is c for d, n, c in cached[1]):
+            cached = None
+        if cached is None:
             skip = ("pos_embed", "head.")
             slots = []
             for n, _ in self.named_parameters():
@@ -303,8 +311,9 @@ class VisionTransformer(nn.Module):
                     continue
                 prefix, _, key = n.rpartition(".")
                 slots.append((self.get_submodule(prefix) if prefix else self, key, n))
-            self.__dict__["_param_slots"] = slots
-        return [(n, mod._parameters[key]) for mod, key, n in slots]
+            edges = [(mod._modules, cn, child) for _, mod in self.named_modules() for cn, child in mod._modules.items()]
+            cached = self.__dict__["_param_slots"] = (slots, edges)
+        return [(n, p) for mod, key, n in cached[0] if (p := mod._parameters.get(key)) is not None]
 
     def _engine(self, device):
         if self.training and self._drop_any:
@@ -406,50 +415,63 @@ class VisionTransformer(nn.Module):
     def _run_auto_graph(self, x, eng, kw):
         """The replayed result, or None when this call should run launch by launch: a (shape, outputs, query_rows tensor)
         combination is captured the SECOND time it is seen — a loop over differently sized tiles, or one that builds a new
-        query_rows tensor per call, never pays for warm-ups and captures it would not reuse."""
+        query_rows tensor per call, never pays for warm-ups and captures it would not reuse.
+        The static input / output buffers of a capture belong to the (thread, stream) that made it (both are part of the
+        key), and capture + replay run under one lock per model, so two threads or streams driving the same model neither
+        share buffers nor see each other's `_graph_suspended` window."""
         qr = kw.get("query_rows")
+        cur = torch.cuda.current_stream(x.device)
         key = (tuple(x.shape), x.device, id(eng), self.__dict__.get("_engine_epoch", 0), self._precision, self._gray_fold,
-               self.pos_embed.data_ptr(),
+               eng.option_epoch,  # set_fold_layernorm / set_fuse_layernorm change the launch sequence a capture froze
+               threading.get_ident(), cur.cuda_stream, self.pos_embed.data_ptr(),
                self.pos_embed._version, kw.get("flags"), kw.get("n_last"), None if qr is None else (id(qr), qr._version))
-        cache = self.__dict__.setdefault("_auto_graphs", {})
-        ent = cache.get(key)
-        if ent is None:
-            seen = self.__dict__.setdefault("_auto_seen", {})
-            if key not in seen:
-                if len(seen) >= 64:
-                    seen.clear()
-                seen[key] = qr  # (keeps the index tensor alive, so its id cannot be reused by another one)
-                return None
-            del seen[key]
-            for k in [k for k in cache if k[2:4] != key[2:4]]:  # captures of engines / parameter uploads that are gone
-                del cache[k]
-            while len(cache) >= self.AUTO_GRAPH_ENTRIES:
-                del cache[next(iter(cache))]
-            xs = x.clone()
-            self.__dict__["_graph_suspended"] = True
-            try:
-                cur = torch.cuda.current_stream(x.device)
-                side = torch.cuda.Stream(device=x.device)
-                side.wait_stream(cur)
-                with torch.cuda.stream(side):  # warm-up off the capturing stream: workspace, LDS opt-ins
-                    for _ in range(2):
-                        self._run(xs, **kw)
-                cur.wait_stream(side)
-                graph = torch.cuda.CUDAGraph()
-                # thread-local capture: HIP calls of the caller's other threads (loaders, pinned copies) stay legal
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    out = self._run(xs, **kw)
-            except RuntimeError:  # a capture this process cannot make: run launch by launch from now on
-                self.auto_graph = False
-                return None
-            finally:
-                self.__dict__["_graph_suspended"] = False
-            # everything the captured launches point at stays alive with the capture
-            ent = cache[key] = (graph, xs, out, (eng, list(eng._ws.values()), dict(self._pos_cache), qr))
-        graph, xs, out, _ = ent
-        xs.copy_(x)
-        graph.replay()
-        return _tree_map(torch.clone, out)
+        lock = self.__dict__.get("_auto_lock")
+        if lock is None:
+            lock = self.__dict__.setdefault("_auto_lock", threading.RLock())
+        with lock:
+            cache = self.__dict__.setdefault("_auto_graphs", {})
+            ent = cache.get(key)
+            if ent is None:
+                seen = self.__dict__.setdefault("_auto_seen", {})
+                if key not in seen:
+                    if len(seen) >= 64:
+                        seen.clear()
+                    seen[key] = qr  # (keeps the index tensor alive, so its id cannot be reused by another one)
+                    return None
+                del seen[key]
+                for k in [k for k in cache if k[2:4] != key[2:4]]:  # captures of engines / parameter uploads that are gone
+                    del cache[k]
+                while len(cache) >= self.AUTO_GRAPH_ENTRIES:
+                    del cache[next(iter(cache))]
+                with torch.inference_mode(False):  # a normal tensor: a later copy_ outside inference mode stays legal
+                    xs = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+                xs.copy_(x)
+                self.__dict__["_graph_suspended"] = True
+                try:
+                    side = torch.cuda.Stream(device=x.device)
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):  # warm-up off the capturing stream: workspace, LDS opt-ins
+                        for _ in range(2):         # (an engine error here is the caller's to see: not caught)
+                            self._run(xs, **kw)
+                    cur.wait_stream(side)
+                    graph = torch.cuda.CUDAGraph()
+                    try:
+                        # thread-local capture: HIP calls of the caller's other threads (loaders, pinned copies) stay legal
+                        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                            out = self._run(xs, **kw)
+                    except RuntimeError as exc:  # a capture this process cannot make: run launch by launch from now on
+                        warnings.warn(f"automatic HIP-graph replay switched off for this model (capture failed: {exc})",
+                                      RuntimeWarning, stacklevel=3)
+                        self.auto_graph = False
+                        return None
+                finally:
+                    self.__dict__["_graph_suspended"] = False
+                # everything the captured launches point at stays alive with the capture
+                ent = cache[key] = (graph, xs, out, (eng, list(eng._ws.values()), dict(self._pos_cache), qr))
+            graph, xs, out, _ = ent
+            xs.copy_(x)
+            graph.replay()
+            return _tree_map(torch.clone, out)
 
     # ---- reference methods ------------------------------------------------------------------
     def interpolate_pos_encoding(self, x, w, h):

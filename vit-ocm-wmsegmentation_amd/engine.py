@@ -81,6 +81,7 @@ class Engine:
         with torch.cuda.device(self.device):
             check(self.lib.ocm_vit_create(C.byref(self.cfg), C.byref(self._h)))
         self._ws = {}
+        self.option_epoch = 0  # bumped by every set_* option: captured launch sequences (module-level replay) are stale then
         self.hip_graph = {"1": True, "auto": "auto"}.get(os.environ.get("OCM_HIP_GRAPH", "0"), False)
         if os.environ.get("OCM_FUSE_LN"):  # "auto" / "never" / "always" (A/B runs; the default is "auto")
             self.set_fuse_layernorm(os.environ["OCM_FUSE_LN"])
@@ -202,6 +203,7 @@ class Engine:
         embedding width has the full-row GEMM + LayerNorm kernel). All three give bit-identical results."""
         value = {"auto": 0, "never": 1, "always": 2}[mode]
         check(self.lib.ocm_vit_set_option(self._h, _lib.OCM_OPT_FUSE_LN, value))
+        self.option_epoch += 1
 
     def set_fold_layernorm(self, on):
         """Per-handle option OCM_OPT_FOLD_LN (split-bf16 engines): True / "auto" (default) hands the residual stream to the
@@ -210,6 +212,7 @@ class Engine:
         fused GEMM + LayerNorm kernels, see set_fuse_layernorm)."""
         value = 2 if on == "always" else 0 if on in (True, "auto") else 1
         check(self.lib.ocm_vit_set_option(self._h, _lib.OCM_OPT_FOLD_LN, value))
+        self.option_epoch += 1
 
     def graph_stats(self):
         """(replays, captures) of the hipGraph path."""

@@ -232,23 +232,38 @@ class SlidingWindowAttention:
     @staticmethod
     def auto_batch_plan(count, n_tokens, cus, max_batch=24, dim=384):
         """Balanced batches (sizes differ by at most one, none above `max_batch`) whose count is chosen for the kernels
-        rather than fixed. A forward is charged the rows its dominant GEMM really occupies the chip for: while the
-        (rows x dim) output holds fewer than 512 tiles of 128 x 128 (and rows >= 8192) the engine runs attn.proj /
-        mlp.fc2 fused with the following LayerNorm on 64-row tiles, one workgroup per CU — whole rounds of
-        ceil(rows / 64) tiles over the CUs; otherwise mlp.fc1's 128 x 128 tiles, two workgroups per CU — whole rounds
-        of ceil(rows / 128) * (4 dim / 128) tiles over 2 CUs slots. The plan with the lowest charge wins (ties: fewer
-        forwards). Measured on one MI355X (split-bf16, 900 windows of 2305 tokens): with every forward on the fused
-        kernels 16 / 21 / 22 windows per forward took 615 / 556 / 599 ms per sweep (2.25 / 2.96 / 3.1 rounds); with
-        the 128 x 128 tiles that large forwards now get, 16 .. 32 windows per forward all land within 522 .. 536 ms."""
+        rather than fixed. A forward is charged the rows its two MLP GEMMs (equal FLOPs, together the largest share of a
+        forward) really occupy the chip for, priced by the tiles the engine dispatches in split-bf16 precision
+        (csrc/gemm_kernels.h, launch_linear_epi):
+          mlp.fc1 (N = 4 dim): 128 x 128 tiles, two workgroups per CU -> whole rounds of ceil(rows / 128) * (4 dim / 128)
+                               tiles over 2 * CUs slots;
+          mlp.fc2 (N = dim):   128 x 192 tiles, one workgroup per CU, when dim is one or two such tiles wide and either the
+                               128 x 128 grid has fewer than 512 tiles or the 192-wide grid fills its last round >= 10 %
+                               better; otherwise 128 x 128 tiles, two per CU.
+        The plan with the lowest charge wins (ties: fewer forwards). Measured on one MI355X (split-bf16, 900 windows of 2305
+        tokens): 16 .. 32 windows per forward all land within 522 .. 536 ms per sweep; a plan that spills fc1 into a
+        nearly empty extra round (22 windows: 9.1 rounds) costs 3-7 %."""
         if count <= 0:
             return []
+        cus = max(1, cus)
+
+        def rounds(tiles, slots):
+            return -(-tiles // slots)
 
         def charge(b):
             rows = b * n_tokens
-            if dim in (128, 256, 384, 512) and rows >= 8192 and -(-rows // 128) * (dim // 128) < 512:
-                return -(-(-(-rows // 64)) // max(1, cus)) * 64 * cus
-            cols = max(1, 4 * dim // 128)
-            return -(-(-(-rows // 128) * cols) // (2 * max(1, cus))) * (2 * cus) * 128 / cols
+            rb = -(-rows // 128)
+            cols1 = max(1, 4 * dim // 128)
+            fc1 = rounds(rb * cols1, 2 * cus) * (2 * cus) * 128 / cols1  # rows the launch occupies the chip for
+            t128 = rb * -(-dim // 128)
+            fc2 = rounds(t128, 2 * cus) * (2 * cus) * 128 / -(-dim // 128)
+            if dim % 192 == 0 and dim // 192 <= 2 and rows >= 4096:
+                t192 = rb * (dim // 192)
+                e192 = t192 / (cus * rounds(t192, cus))
+                e128 = t128 / (2 * cus * rounds(t128, 2 * cus))
+                if t128 < 512 or e192 > 1.1 * e128:
+                    fc2 = rounds(t192, cus) * cus * 128 / (dim // 192)
+            return 0.5 * (fc1 + fc2)
 
         best = None
         nb_min = -(-count // max(1, max_batch))
