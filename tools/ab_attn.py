@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Development: the split-bf16 attention kernel variants against each other, stand-alone (GPU box, development library).
+
+    OCM_VIT_LIB=exp_libs/libocm_vit_dev.so python tools/ab_attn.py [--variants 0,3]
+
+For every shape: bit-identity of context rows and log-sum-exp between knob 6 = 0 (the shipped dispatch: attn_fwd_x3_pp_kernel,
+software-pipelined blocks, for N <= 1024; attn_fwd_x3_dma_kernel on eight waves above that) and the other variants (3 = the
+round-3 loop attn_fwd_x3_dma_kernel on four waves, 1 = the register-staged kernel), NaN-poisoned padding; then alternating
+timings with hipEvents (median of rounds). In-forward numbers: tools/ab_bench.sh "6=0" "6=3".
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("OCM_VIT_LIB", os.path.join(ROOT, "exp_libs", "libocm_vit_dev.so"))
+import torch  # noqa: E402
+
+from vit_ocm_wmsegmentation_amd import _lib  # noqa: E402
+from vit_ocm_wmsegmentation_amd.engine import _p, to_operand  # noqa: E402
+
+X3 = _lib.OCM_PREC_BF16X3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", default="0,3")
+    ap.add_argument("--rounds", type=int, default=7)
+    a = ap.parse_args()
+    variants = [int(v) for v in a.variants.split(",")]
+    lib = _lib.load()
+    raw = C.CDLL(os.environ["OCM_VIT_LIB"])
+    dev = torch.device("cuda:0")
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+
+    def knob(v):
+        assert raw.ocm_debug_knob(6, v) == 0
+
+    def operands(B, N, H, sharp, seed=60):
+        g = torch.Generator().manual_seed(seed)
+        q = (torch.randn((B * H, N, 64), generator=g) * sharp).to(dev)
+        k = (torch.randn((B * H, N, 64), generator=g) * sharp).to(dev)
+        v = torch.randn((B * H, N, 64), generator=g).to(dev)
+        npad = lib.ocm_n_pad_prec(X3, N)
+        nan = float("nan")
+        qp = torch.full((B * H, npad, 64), nan, device=dev)
+        kp = torch.full((B * H, npad, 64), nan, device=dev)
+        vp = torch.full((B * H, 64, npad), nan, device=dev)
+        qp[:, :N], kp[:, :N], vp[:, :, :N] = q, k, v.transpose(1, 2)
+        return to_operand(qp, X3), to_operand(kp, X3), to_operand(vp, X3)
+
+    def run(qs, ks, vs, B, N, H, want_ctx=True):
+        ctx = torch.full((B, N, H * 64), -1, dtype=torch.int32, device=dev) if want_ctx else None
+        lse = torch.full((B * H, N), float("nan"), device=dev)
+        _lib.check(lib.ocm_op_attention(X3, _p(qs), _p(ks), _p(vs), _p(ctx), _p(lse), B, N, H, 0.125, st()))
+        torch.cuda.synchronize()
+        return ctx, lse
+
+    ok = True
+    for (B, N, H, sharp) in [(1, 32, 1, 1.0), (2, 33, 2, 2.0), (2, 65, 3, 1.0), (1, 96, 2, 3.0), (4, 197, 6, 2.0), (64, 197, 6, 1.0),
+                             (2, 577, 4, 2.0), (1, 1025, 2, 1.0), (3, 2305, 6, 2.0), (1, 2305, 6, 1.0), (2, 1056, 3, 1.0)]:
+        qs, ks, vs = operands(B, N, H, sharp)
+        knob(0)
+        c0, l0 = run(qs, ks, vs, B, N, H)
+        _, l0s = run(qs, ks, vs, B, N, H, want_ctx=False)
+        for v in variants[1:]:
+            knob(v)
+            c1, l1 = run(qs, ks, vs, B, N, H)
+            _, l1s = run(qs, ks, vs, B, N, H, want_ctx=False)
+            same = torch.equal(c0, c1) and torch.equal(l0, l1) and torch.equal(l0s, l1s) and torch.equal(l1, l1s)
+            ok &= same
+            print(f"B={B} N={N} H={H} sharp={sharp}: variant {v} {'==' if same else '!='} variant 0"
+                  + ("" if same else f"  (ctx diff {int((c0 != c1).sum())}, lse diff {int((l0 != l1).sum())}, stats-only diff {int((l0s != l1s).sum())})"))
+    knob(0)
+    print("bit-identity:", "OK" if ok else "FAILED")
+
+    for (B, N, H) in [(64, 197, 6), (21, 2305, 6), (128, 577, 12), (1, 197, 6)]:
+        qs, ks, vs = operands(B, N, H, 1.0)
+        ctx = torch.empty((B, N, H * 64), dtype=torch.int32, device=dev)
+        lse = torch.empty((B * H, N), device=dev)
+        # something between launches that evicts the operands from L2, as the neighbouring kernels of a forward do
+        spoil = torch.empty(96 << 20, dtype=torch.uint8, device=dev)
+        times = {v: [] for v in variants}
+        for rnd in range(a.rounds + 1):
+            for v in variants:
+                knob(v)
+                spoil.add_(1)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(3):
+                    _lib.check(lib.ocm_op_attention(X3, _p(qs), _p(ks), _p(vs), _p(ctx), _p(lse), B, N, H, 0.125, st()))
+                e1.record()
+                torch.cuda.synchronize()
+                if rnd:
+                    times[v].append(e0.elapsed_time(e1) / 3 * 1e3)
+        flops = 4.0 * B * H * N * N * 64
+        print(f"B={B} N={N} H={H}: " + "  ".join(
+            f"variant {v}: {sorted(t)[len(t) // 2]:.1f} us (min {min(t):.1f}) = {flops / sorted(t)[len(t) // 2] / 1e6:.0f} TFLOP/s" for v, t in times.items()))
+    knob(0)
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

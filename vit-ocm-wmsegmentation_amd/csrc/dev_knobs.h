@@ -5,7 +5,8 @@
 // exp_libs/libocm_vit_dev.so with the knobs (declared in include/ocm_vit_dev.h; load it through OCM_VIT_LIB).
 //   [0] nn.Linear GEMM variant, [1] write-through store mask (0 = shipped mask, -1 = none), [3] qkv GEMM variant,
 //   [4] = 2 fused GEMM+LayerNorm on the LDS-DMA loop, [6] split-bf16 attention 1 = register-staged streaming kernel /
-//   2 = whole-sequence kernel (shipped: LDS-DMA streaming kernel), [7] its 8-wave form 1 = never / 2 = always.
+//   2 = whole-sequence kernel / 3 = the round-3 LDS-DMA loop on four waves (shipped: software-pipelined kernel up to 1 024 tokens,
+//   LDS-DMA streaming kernel on eight waves above), [7] its 8-wave form 1 = never / 2 = always.
 #pragma once
 #ifdef OCM_DEV
 extern int g_ocm_knobs[8];

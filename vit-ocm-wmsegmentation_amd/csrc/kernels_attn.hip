@@ -1112,6 +1112,288 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
 }
 
 
+// ------------------------------------------------------------------------------------------
+// Software-pipelined form of attn_fwd_x3_dma_kernel for four-wave workgroups (64-wide heads, whole key range, N <= 1024:
+// ViT-S/16 and ViT-B/16 tiles). The loop of the kernel above runs QK^T(t) -> softmax(t) -> P.V(t) per key tile: twelve matrix
+// instructions, ~135 vector instructions, twelve matrix instructions, each group waiting for the one before. Here an
+// iteration is two BLOCKS,
+//     M(t): O += V^T(t) . P(t),  then  S = K(t+1) . Q^T      24 matrix instructions back to back, LDS reads only
+//     V(t+1): softmax of S -> P(t+1) (split pairs), running max / sum, rescale of O        vector instructions only
+// so a wave alternates between one long matrix burst and one long vector burst, and the three workgroups a CU holds (not
+// synchronised with each other: three waves per SIMD) fill each other's bursts: the matrix pipe and the vector ALU are
+// separate. ViT-S/16 at B = 64, in the forward, alternating runs on one box: 28.4 -> 27.1 us per launch (stand-alone 29.5 ->
+// 28.2); ViT-B/16 at 384^2 the same either way.
+// LDS: a ring of three 8 KiB K tiles and a ring of three 8 KiB V^T tiles (M(t) reads V^T(t) and K(t+1)). Batch t of LDS-DMA
+// = {K(t+3), V^T(t+2)} is issued right after the barrier that opens iteration t — into the slots of K(t) and V^T(t-1), whose
+// last readers finished before that barrier — and waited for (counted vmcnt: everything but batch t) in front of the barrier
+// that closes iteration t, one whole iteration before its first reader. One barrier per tile, as before.
+// The context rows leave as 16-byte stores: a lane holds four consecutive channels per accumulator group, v_permlane32_swap
+// between the two lane halves (same query) makes them eight.
+// Same arithmetic per key and the same order of accumulation as attn_fwd_x3_dma_kernel: bit-identical results
+// (tools/ab_attn.py checks every shape class with NaN-poisoned padding).
+// Measured and NOT shipped (round 4, git history has both): (i) the same blocks with EIGHT waves whose halves run them in
+// opposite phases (waves 0-3 in M while waves 4-7 are in V, a barrier between blocks): S, P, O and Q^T live at once need 209-237
+// registers, i.e. ONE workgroup per CU where the kernel above (128 registers) runs two — N = 2305, 21 windows: 502 -> 683-787 us
+// per launch; forced into 128 registers it spills 105-276 of them. (ii) The kernel above with waves 4-7 half a tile behind
+// waves 0-3 (two barriers per tile, 128 registers, two workgroups per CU): 503 -> 527 us. Two independent workgroups per CU
+// already interleave the way a ping-pong would; the extra barrier only costs.
+template <bool WANT_O>
+__global__ __launch_bounds__(256, 3) void attn_fwd_x3_pp_kernel(const char *__restrict__ Q, const char *__restrict__ Kk,
+                                                               const char *__restrict__ Vt, char *__restrict__ ctx,
+                                                               float *__restrict__ lse2, int N, int npad, int H, float scale2) {
+    constexpr int NW = 4, HD = 64, KB = HD * 128, KP = 8 / NW, VP = WANT_O ? 8 / NW : 0;  // KB: bytes of a 32-key tile of K (or V^T)
+    __shared__ __attribute__((aligned(1024))) char smem[6 * KB];  // K slots 0..2 | V^T slots 0..2
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    int qblk, bh;
+    xcd_remap2(qblk, bh);
+    const int q0 = (qblk * NW + wave) * 32;
+    const bool active = q0 < N;  // wave-uniform
+    const char *Qb = Q + (int64_t)bh * npad * (HD * 4);
+    const char *Kb = Kk + (int64_t)bh * npad * (HD * 4);
+    const char *Vb = Vt + (int64_t)bh * HD * npad * 4;
+    const int nt = (N + 31) >> 5;
+
+    bf16x8 qh[4], ql[4];  // Q^T as the B operand (issued first: the prologue's wait covers it)
+    {
+        const char *qp = Qb + (int64_t)min(q0 + r, N - 1) * (HD * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const char *p = qp + (s >> 1) * 128 + ((s & 1) * 16 + 8 * h) * 2;
+            qh[s] = *(const bf16x8 *)p;
+            ql[s] = *(const bf16x8 *)(p + 64);
+        }
+    }
+    int voffK[KP], voffV[VP ? VP : 1];
+    {
+        const int lrow = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            const int pc = j * NW + wave, rho = (pc & 3) * 8 + lrow;
+            voffK[j] = rho * (HD * 4) + (pc >> 2) * 128 + ((slot ^ ((rho >> 1) & 7)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < VP; ++j) {
+            const int rho = (j * NW + wave) * 8 + lrow;
+            voffV[j] = rho * npad * 4 + ((slot ^ ((rho >> 1) & 7)) << 4);
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, (unsigned)(npad * HD * 4), 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, (unsigned)(HD * npad * 4), 0x00020000);
+#define OCM_PP_DMA_K(t, slot)                                                                                        \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < KP; ++j)                                                               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(smem + (slot) * KB + (j * NW + wave) * 1024), 16, \
+                                                     voffK[j], (t) * (32 * HD * 4), 0, 0);                           \
+    } while (0)
+#define OCM_PP_DMA_V(t, slot)                                                                                              \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < VP; ++j)                                                                     \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(smem + (3 + (slot)) * KB + (j * NW + wave) * 1024), 16, \
+                                                     voffV[j], (t) * 128, 0, 0);                                           \
+    } while (0)
+#else
+#define OCM_PP_DMA_K(t, slot) (void)0
+#define OCM_PP_DMA_V(t, slot) (void)0
+#endif
+    // prologue: K(0..2), V^T(0..1) — the batches -3 .. -1
+    OCM_PP_DMA_K(0, 0);
+    if (nt > 1) OCM_PP_DMA_K(1, 1);
+    if (WANT_O) OCM_PP_DMA_V(0, 0);
+    if (nt > 2) OCM_PP_DMA_K(2, 2);
+    if (WANT_O && nt > 1) OCM_PP_DMA_V(1, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) through the builtin: hipcc must know the Q registers are complete
+    // a workgroup barrier that leaves the vector-memory counter alone (LDS-DMA stays in flight across it) and that nothing is
+    // scheduled across
+    auto block_barrier = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    block_barrier();  // everybody's prologue pieces have landed
+
+    f32x16 O[2], S;
+    bf16x8 ph[2], pl[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[0][e] = O[1][e] = S[e] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ph[s2][e] = pl[s2][e] = (bf16)0.f;
+    float m = -INFINITY, l = 0.f;
+    const int pr = pi_row(r);
+    const int first_pad = N - (nt - 1) * 32;  // valid keys of the last tile (1..32)
+
+    // S = K(tile in K slot `ks`) . Q^T
+    auto qk = [&](int ks) {
+        const char *Kt = smem + ks * KB;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const char *kp = Kt + (s >> 1) * 4096;
+            const bf16x8 kh = *(const bf16x8 *)(kp + lds_off(pr, (s & 1) * 2 + h));
+            const bf16x8 kl = *(const bf16x8 *)(kp + lds_off(pr, 4 + (s & 1) * 2 + h));
+            S = mfma32x3(kh, kl, qh[s], ql[s], S);
+        }
+    };
+    // block M(t): P.V of tile t (V^T slot vs), then the scores of tile t + 1 (K slot ks) — P's registers are free for them
+    auto Mblk = [&](int vs, int ks, bool more) {
+        if (WANT_O) {
+            const char *Vtile = smem + (3 + vs) * KB;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char *vp = Vtile + db * 32 * 128;
+                    const bf16x8 vh = *(const bf16x8 *)(vp + lds_off(r, 2 * s2 + h));
+                    const bf16x8 vl = *(const bf16x8 *)(vp + lds_off(r, 4 + 2 * s2 + h));
+                    O[db] = mfma32x3(vh, vl, ph[s2], pl[s2], O[db]);
+                }
+        }
+        if (more) qk(ks);
+    };
+    // block V(t): softmax of the scores in S (tile t), P as split pairs
+    auto Vblk = [&](bool last_of_seq) {
+        if (last_of_seq && first_pad < 32) {  // padding keys -> -inf (wave-uniform branch)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (key_of_reg(e, h) >= first_pad) S[e] = -INFINITY;
+        }
+        float mx = S[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, S[e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx * scale2);  // finite: every tile holds at least one valid key
+        const float alpha = fast_exp2(m - mn);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = fast_exp2(fmaf(S[e], scale2, -mn));
+            S[e] = p;
+            ps += p;
+        }
+        l = fmaf(l, alpha, ps);
+        if (WANT_O) {
+            if (__any(alpha != 1.0f)) {  // the running max moved somewhere in this wave
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    O[0][e] *= alpha;
+                    O[1][e] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = S[8 * s2 + e];
+                    const bf16 t = (bf16)pv;
+                    ph[s2][e] = t;
+                    pl[s2][e] = (bf16)(pv - (float)t);
+                }
+        }
+    };
+
+    if (active) {
+        qk(0);
+        Vblk(nt == 1);
+    }
+    // the first batch of the loop (K(3) into the slot of K(0)) must stay behind everybody's prologue scores
+    block_barrier();
+
+    int s0 = 0, s1 = 1;  // slot of tile kt / kt + 1 (both rings: tile t lives in slot t % 3)
+    for (int kt = 0; kt < nt; ++kt) {
+        const int s2n = s1 == 2 ? 0 : s1 + 1;  // slot of tile kt + 2 (= the slot tile kt - 1 had)
+        // batch kt: K(kt+3) into the slot of K(kt), V^T(kt+2) into the slot of V^T(kt-1): everybody is past their readers
+        if (kt + 3 < nt) OCM_PP_DMA_K(kt + 3, s0);
+        if (WANT_O && kt + 2 < nt) OCM_PP_DMA_V(kt + 2, s2n);
+        const bool last = kt + 1 == nt;
+        if (WANT_O && last && first_pad < 32) {
+            // zero the V^T columns of the padding keys of the last tile (it has landed: waited for in front of the previous
+            // barrier; the qkv epilogue never writes them and 0 * garbage must not be NaN)
+            const int kc = tid & 3;
+            if (kc * 8 + 8 > first_pad) {
+                char *Vtile = smem + (3 + s0) * KB;
+                const int d = tid >> 2;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    bf16x8 *p = (bf16x8 *)(Vtile + lds_off(d, half * 4 + kc));
+                    bf16x8 t = *p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (kc * 8 + e >= first_pad) t[e] = (bf16)0.f;
+                    *p = t;
+                }
+            }
+            block_barrier();
+        }
+        if (active) {
+            Mblk(s0, s1, !last);
+            if (!last) Vblk(kt + 2 == nt);
+        }
+        // everything but batch kt has landed (this wave's pieces; the barrier makes it everybody's)
+        if (kt + 3 < nt)
+            OCM_VMCNT_ATTN(KP + VP);
+        else if (WANT_O && kt + 2 < nt)
+            OCM_VMCNT_ATTN(VP);
+        else
+            OCM_VMCNT_ATTN(0);
+        block_barrier();
+        s0 = s1;
+        s1 = s2n;
+    }
+#undef OCM_PP_DMA_K
+#undef OCM_PP_DMA_V
+
+    if (!active) return;
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const int qrow = q0 + r;
+    if (lse2 && h == 0 && qrow < N) lse2[(int64_t)bh * N + qrow] = m + __log2f(lt);
+    if (WANT_O) {
+        const float inv = 1.0f / lt;
+        const int b = bh / H, head = bh - b * H;
+        char *dst = ctx + ((int64_t)b * N + min(qrow, N - 1)) * (H * HD) * 4 + head * (HD * 4);
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                f32x4 oa, ob;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    oa[e] = O[db][4 * g + e] * inv;
+                    ob[e] = O[db][4 * g + 4 + e] * inv;
+                }
+                bf16x4 ah, al, bhh, bl;
+                split4(oa, ah, al);
+                split4(ob, bhh, bl);
+                uint2 ahu = __builtin_bit_cast(uint2, ah), alu = __builtin_bit_cast(uint2, al);
+                uint2 bhu = __builtin_bit_cast(uint2, bhh), blu = __builtin_bit_cast(uint2, bl);
+                // lanes 32-63 of the first operand swap with lanes 0-31 of the second: the lower lanes end with channels
+                // 8g .. 8g+7 (own | partner's), the upper lanes with 8g+8 .. 8g+15 (partner's | own)
+                auto sw = [](unsigned &x, unsigned &y) {
+                    const auto rr = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+                    x = rr[0];
+                    y = rr[1];
+                };
+                sw(ahu.x, bhu.x);
+                sw(ahu.y, bhu.y);
+                sw(alu.x, blu.x);
+                sw(alu.y, blu.y);
+                if (qrow < N) {
+                    char *p = dst + db * 128 + (8 * g + 8 * h) * 2;
+                    *(uint4 *)p = make_uint4(ahu.x, ahu.y, bhu.x, bhu.y);
+                    *(uint4 *)(p + 64) = make_uint4(alu.x, alu.y, blu.x, blu.y);
+                }
+            }
+    }
+}
+
 // Combines the key slices of attn_fwd_x3_dma_kernel<..., KSPLIT>: 16 lanes per query row (four channels each),
 //   m = max_s m_s,  L = sum_s l_s 2^(m_s - m),  ctx = sum_s O_s 2^(m_s - m) / L  (as split pairs),  lse2 = m + log2 L.
 template <int HD>
@@ -1598,8 +1880,14 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
 #endif
         if (wide) {
             if (ctx) OCM_X3_ATTN_DMA(true, 8, 2, grid8, block8); else OCM_X3_ATTN_DMA(false, 8, 2, grid8, block8);
-        } else {
+        } else if (OCM_KNOB(6) == 3) {  // development A/B: the round-3 loop on four waves (shipped: the software-pipelined kernel)
             if (ctx) OCM_X3_ATTN_DMA(true, 4, 3, grid, block); else OCM_X3_ATTN_DMA(false, 4, 3, grid, block);
+        } else if (ctx) {
+            attn_fwd_x3_pp_kernel<true><<<grid, block, 0, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx, lse2,
+                                                               n_tokens, n_pad, heads, scale * LOG2E);
+        } else {
+            attn_fwd_x3_pp_kernel<false><<<grid, block, 0, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx, lse2,
+                                                                n_tokens, n_pad, heads, scale * LOG2E);
         }
 #undef OCM_X3_ATTN_DMA
 #undef OCM_X3_ATTN
