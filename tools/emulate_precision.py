@@ -44,7 +44,9 @@ def mm(a, b, mode):
 
 
 def forward_attn(sd, cfg, x, mode, modes_by_op=None):
-    mo = lambda op: (modes_by_op or {}).get(op, mode)  # noqa: E731
+    # per-contraction overrides: {"qk": mode} for every layer, {("qk", 11): mode} for one layer (wins over the class entry)
+    layer = [None]
+    mo = lambda op: (modes_by_op or {}).get((op, layer[0]), (modes_by_op or {}).get(op, mode))  # noqa: E731
     p, H, eps = cfg["patch_size"], cfg["num_heads"], cfg["eps"]
     B = x.shape[0]
     D = sd["cls_token"].shape[-1]
@@ -57,6 +59,7 @@ def forward_attn(sd, cfg, x, mode, modes_by_op=None):
     L = cfg["depth"]
     for i in range(L):
         pre = f"blocks.{i}."
+        layer[0] = i
         xn = O.layer_norm(sd, pre + "norm1", x, eps)
         qkv = mm(xn, sd[pre + "attn.qkv.weight"].t(), mo("qkv")) + sd[pre + "attn.qkv.bias"]
         N = x.shape[1]

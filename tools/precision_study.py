@@ -4,6 +4,7 @@
     python tools/precision_study.py conditioning   # fp32 vs float64 reference, split-bf16 emulation, per qkv gain (ViT-B/16 384^2)
     python tools/precision_study.py fp16           # which contractions could run in single fp16 beside split-bf16 (ViT-S/16 peaked)
     python tools/precision_study.py fold           # LayerNorm folded into its consumer GEMM (un-normalised split operands + row sums)
+    python tools/precision_study.py saturated      # which contraction carries the split-bf16 error on the saturated ViT-B set
 
 Every contraction is emulated with its operands rounded the way a mode rounds them (tools/emulate_precision.py) and float64
 accumulation; "fp64" runs the whole forward in float64. Findings recorded in DESIGN.md:
@@ -62,6 +63,35 @@ def study(arch, patch, size, gain, iseed, B=1, modes=("x3",), ops=None):
         print(f"   x3 + {name}: vs fp32 {(a - ref32).abs().max():.3e}", flush=True)
 
 
+def saturated(arch="vit_base", patch=16, size=384, gain=8.0, iseed=99):
+    """Which contraction carries the split-bf16 error on the SATURATED softmax (`vitb16_384_saturated`: attention max 1.0000)?
+    Everything in float64 except ONE contraction class (or one layer's instance of it) with split-bf16 operands."""
+    sd, cfg, x = _setup(arch, patch, size, gain, iseed)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    L = cfg["depth"]
+    ref64 = E.forward_attn(sd64, cfg, x.double(), "fp64")
+    ref32 = E.forward_attn(sd, cfg, x, "fp32")
+    allx3 = E.forward_attn(sd, cfg, x, "x3")
+    print(f"{arch}/{patch} {size} gain {gain}: attention max {ref32.max():.4f}; fp32 reference vs float64 "
+          f"{(ref32.double() - ref64).abs().max():.3e}; all contractions split-bf16 vs float64 {(allx3.double() - ref64).abs().max():.3e} "
+          f"(vs the fp32 reference {(allx3 - ref32).abs().max():.3e})", flush=True)
+
+    def one(label, overrides):
+        a = E.forward_attn(sd64, cfg, x.double(), "fp64", overrides)
+        print(f"   float64 except {label:44s}: {(a.double() - ref64).abs().max():.3e}", flush=True)
+    for op in ("patch", "qkv", "qk", "pv", "proj", "fc1", "fc2"):
+        one(f"{op} (all layers) in split-bf16", {op: "x3"})
+    last = L - 1
+    one("qkv of the LAST block only", {("qkv", last): "x3"})
+    one("Q.K^T of the LAST block only", {("qk", last): "x3"})
+    one("qkv + Q.K^T of the LAST block", {("qkv", last): "x3", ("qk", last): "x3"})
+    every = {op: "x3" for op in ("patch", "qkv", "qk", "pv", "proj", "fc1", "fc2")}
+    one("everything BUT the last block's qkv + Q.K^T", {**every, ("qkv", last): "fp64", ("qk", last): "fp64"})
+    one("everything BUT the last block's Q.K^T", {**every, ("qk", last): "fp64"})
+    for lay in (0, L // 2, last - 1):
+        one(f"all contractions of block {lay} only", {(op, lay): "x3" for op in ("qkv", "qk", "pv", "proj", "fc1", "fc2")})
+
+
 def forward_folded(sd, cfg, x):
     """out = rstd * (split(x) . split(W * gamma)^T - mu * c) + d for attn.qkv and mlp.fc1; everything else as the x3 mode."""
     p, H, eps = cfg["patch_size"], cfg["num_heads"], cfg["eps"]
@@ -114,6 +144,9 @@ def main():
                "qkv in fp16": {"qkv": "h1"}, "Q.K^T in fp16": {"qk": "h1"}}
         study("vit_small", 16, 224, 8.0, 1234, B=2, modes=("x3", "h1", "bf16"), ops=ops)
         study("vit_base", 16, 384, 6.5, 99, ops={"fc1 + fc2 in fp16": {"fc1": "h1", "fc2": "h1"}})
+    elif which == "saturated":
+        saturated()
+        saturated("vit_base", 16, 384, 6.5, 99)  # the calibrated (unsaturated) set of the same geometry, for scale
     elif which == "fold":
         fold("vit_small", 16, 224, 8.0, 1234, B=2)
         fold("vit_small", 16, 224, 8.0, 1234, B=2, shift=0.5)

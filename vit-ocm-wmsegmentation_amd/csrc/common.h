@@ -96,6 +96,27 @@ __device__ __forceinline__ f32x16 mfma32x3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
 }
 
+// The same product on v_mfma_f32_16x16x32_bf16 (gemm_core.h: GemmCfg::MF16): a 16 x 16 tile per instruction, K = 32 — one whole
+// 128-byte LDS row segment of hi (or lo) halves per step. Lane l holds A[row l & 15][k = 8 (l >> 4) + j] and
+// B[k = 8 (l >> 4) + j][col l & 15]; C/D: col = l & 15, row = 4 (l >> 4) + reg.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4_t mfma16x3(bf16x8 ah, bf16x8 al, bf16x8 bh, bf16x8 bl, f32x4_t c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+// Accumulator layouts of a 32 x 32 output tile held as f32x16 per lane. ACCL 0: one 32x32x16 accumulator (register -> row
+// acc_row32, lane & 31 -> column). ACCL 1: four 16x16x32 accumulators, sub-tile q = 2 * (row half) + (column half) in
+// registers 4q .. 4q+3. rpos = coordinate along the register-indexed axis, cpos = along the lane-indexed axis.
+template <int ACCL>
+__device__ __forceinline__ int acc_rpos(int e, int lane) {
+    return ACCL ? 16 * (e >> 3) + 4 * ((lane >> 4) & 3) + (e & 3) : acc_row32(e, lane >> 5);
+}
+template <int ACCL>
+__device__ __forceinline__ int acc_cpos(int e, int lane) {
+    return ACCL ? 16 * ((e >> 2) & 1) + (lane & 15) : (lane & 31);
+}
+
 // Bijective XCD-aware remap of a linear workgroup id: consecutive logical ids
 // (which share an A row panel) land on one XCD / one L2. Speed only.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -42,9 +42,14 @@ __device__ unsigned long long g_stamps[8192 * 8];
 #define WSTAMP(k) ((void)0)
 #endif
 
-template <int BM_, int BN_, int WAVES_M_, int WAVES_N_>
+// MF16_: split-bf16 products on v_mfma_f32_16x16x32_bf16 (four 16 x 16 accumulators per 32 x 32 tile) instead of 32x32x16 — the
+// same LDS bytes and the same matrix cycles per product; the chip holds a higher clock on it (MI355X_MICROARCH.md, DVFS
+// give-back item 7). Pays where the matrix pipe is the busier resource: the 128 x 128 tiles with two workgroups per CU
+// (ViT-S/16 B = 64 in the forward, alternating libraries on one box: mlp.fc1 52.2 -> 49.8 us, attn.qkv 43.1 -> 41.6); the
+// one-per-CU 128 x 192 tiles (LDS-port-bound) measure the same and the register-staged patch embedding loses (55 -> 68 us).
+template <int BM_, int BN_, int WAVES_M_, int WAVES_N_, int MF16_ = 0>
 struct GemmCfg {
-    static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_;
+    static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, MF16 = MF16_;
     static constexpr int NT = WAVES_M * WAVES_N * OCM_WAVE;
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     static constexpr int TM = WM / 32, TN = WN / 32;
@@ -92,6 +97,12 @@ struct Elem<sp32> {
     static constexpr int MODE = 2, KROW = 32, EPW = 8;
 };
 
+// accumulator layout of element type E's main loop (common.h: acc_rpos / acc_cpos)
+template <class Cfg, class E>
+constexpr int accl_of() {
+    return (Elem<E>::MODE == 2 && Cfg::MF16) ? 1 : 0;
+}
+
 // A operand = row-major activations of element type E (lda in elements).
 template <class E>
 struct RowLoader {
@@ -115,7 +126,43 @@ template <class Cfg, class E, bool SWAP>
 __device__ __forceinline__ void mma_step(const char *Ab, const char *Bb, int r, int h,
                                          f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
-    if constexpr (Elem<E>::MODE == 2) {
+    if constexpr (Elem<E>::MODE == 2 && Cfg::MF16) {
+        // split-bf16 on 16x16x32: lane (row r & 15 of a 16-row half, k chunk g) reads hi chunk g / lo chunk 4 + g of its row —
+        // the whole K step in one instruction per (half, part); twelve MFMAs per 32 x 32 tile and step, four accumulators
+        const int r16 = r & 15, g = (r >> 4) + 2 * h;
+        bf16x8 ah[TM][2], al[TM][2], bh[TN][2], bl[TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int ra = 0; ra < 2; ++ra) {
+                ah[i][ra] = *(const bf16x8 *)(Ab + i * Cfg::RB * 128 + lds_off(ra * 16 + r16, g));
+                al[i][ra] = *(const bf16x8 *)(Ab + i * Cfg::RB * 128 + lds_off(ra * 16 + r16, 4 + g));
+            }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                bh[j][cb] = *(const bf16x8 *)(Bb + j * Cfg::CB * 128 + lds_off(cb * 16 + r16, g));
+                bl[j][cb] = *(const bf16x8 *)(Bb + j * Cfg::CB * 128 + lds_off(cb * 16 + r16, 4 + g));
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // sub-tile q: register-indexed half q >> 1, lane-indexed half q & 1. Normal: registers = rows (A), lanes =
+                    // columns (B); SWAP: registers = n (B rows as the first operand), lanes = m
+                    f32x4_t c = __builtin_shufflevector(acc[i][j], acc[i][j], 0, 1, 2, 3);
+                    if (q == 1) c = __builtin_shufflevector(acc[i][j], acc[i][j], 4, 5, 6, 7);
+                    if (q == 2) c = __builtin_shufflevector(acc[i][j], acc[i][j], 8, 9, 10, 11);
+                    if (q == 3) c = __builtin_shufflevector(acc[i][j], acc[i][j], 12, 13, 14, 15);
+                    c = SWAP ? mfma16x3(bh[j][q >> 1], bl[j][q >> 1], ah[i][q & 1], al[i][q & 1], c)
+                             : mfma16x3(ah[i][q >> 1], al[i][q >> 1], bh[j][q & 1], bl[j][q & 1], c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = c[e];
+                }
+    } else if constexpr (Elem<E>::MODE == 2) {
         // split-bf16: the 128-byte row is [hi k 0..31 | lo k 0..31]; two k16 sub-steps, three MFMAs per product.
         // (hipcc interleaves these reads and MFMAs in groups of three to five reads followed by lgkmcnt(0); pinning a
         // rolling window of reads two blocks ahead of the MFMAs with sched_group_barrier was measured on the 64 x 384
@@ -239,22 +286,15 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
 
     // Accumulators start at the bias (one load per column / register row, issued together with the
     // first operand tile): the epilogues then add nothing and issue no dependent global loads.
+    constexpr int ACCL = accl_of<Cfg, E>();
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nb = n0 + (j * Cfg::WAVES_N + wn) * 32;
-        if (!SWAP) {
-            const float bv = bias ? bias[min(nb + r, N - 1)] : 0.f;  // lane = output column
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+        for (int e = 0; e < 16; ++e) {  // normal: the lane-indexed axis is the output column; SWAP: the register-indexed one
+            const float bv = bias ? bias[min(nb + (SWAP ? acc_rpos<ACCL>(e, lane) : acc_cpos<ACCL>(e, lane)), N - 1)] : 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = bv;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {  // registers = output column
-                const float bv = bias ? bias[min(nb + acc_row32(e, h), N - 1)] : 0.f;
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i][j][e] = bv;
-            }
+            for (int i = 0; i < TM; ++i) acc[i][j][e] = bv;
         }
     }
 
@@ -463,13 +503,15 @@ __device__ __forceinline__ void gemm_mainloop_dma(const E *__restrict__ A, int64
 
     // accumulators start at the bias (see gemm_mainloop): the bias loads are issued first (oldest), the prologue
     // DMAs next, and the accumulators are filled while those are in flight
-    float bv[TN][SWAP ? 16 : 1];
+    constexpr int ACCL = accl_of<Cfg, E>();
+    constexpr int NBV = SWAP ? 16 : (ACCL ? 2 : 1);  // distinct bias values a lane needs per tile
+    float bv[TN][NBV];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nb = n0 + (j * Cfg::WAVES_N + wn) * 32;
 #pragma unroll
-        for (int e = 0; e < (SWAP ? 16 : 1); ++e)
-            bv[j][e] = bias ? bias[min(nb + (SWAP ? acc_row32(e, h) : r), N - 1)] : 0.f;
+        for (int e = 0; e < NBV; ++e)
+            bv[j][e] = bias ? bias[min(nb + (SWAP ? acc_rpos<ACCL>(e, lane) : acc_cpos<ACCL>(4 * e, lane)), N - 1)] : 0.f;
     }
 #pragma unroll
     for (int t = 0; t < D; ++t)
@@ -479,7 +521,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(const E *__restrict__ A, int64
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = bv[j][SWAP ? e : 0];
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = bv[j][SWAP ? e : (ACCL ? ((e >> 2) & 1) : 0)];
     int bc = 0, bi = D % NSTAGE;  // stage computed next / stage filled next
 #ifdef OCM_GEMM_STAMPS
     unsigned long long stamp_wait = 0;
@@ -555,7 +597,7 @@ __device__ __forceinline__ auto epi_prefetch(const Epi &epi, int m0, int n0, int
 }
 
 // LDS_AVAIL: bytes of LDS the kernel owns (the register-staged kernels: Cfg::LDS_BYTES; the LDS-DMA kernels: their ring)
-template <class Cfg, bool SWAP, class Epi, int LDS_AVAIL = Cfg::LDS_BYTES, class Pre = EpiNoPre>
+template <class Cfg, bool SWAP, class Epi, int LDS_AVAIL = Cfg::LDS_BYTES, class Pre = EpiNoPre, int ACCL = 0>
 __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::TN], char *smem, const Epi &epi, int m0,
                                              int n0, bool active = true, const Pre *pre = nullptr) {
     f32x2 *rowtab = (f32x2 *)(smem + LDS_AVAIL), *coltab = rowtab + Cfg::BM;
@@ -578,9 +620,10 @@ __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::T
             for (int j = 0; j < Cfg::TN; ++j) {
                 const int tm = (i * Cfg::WAVES_M + wm) * 32, tn = (j * Cfg::WAVES_N + wn) * 32;
                 // normal: lane -> column n, registers -> rows m.  swapped: lane -> m, registers -> n.
-                const int row0 = SWAP ? tn : tm, col = (SWAP ? tm : tn) + r;
+                const int row0 = SWAP ? tn : tm, col0 = SWAP ? tm : tn;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) C[(row0 + acc_row32(e, h)) * COLS + col] = acc[i][j][e];
+                for (int e = 0; e < 16; ++e)
+                    C[(row0 + acc_rpos<ACCL>(e, lane)) * COLS + col0 + acc_cpos<ACCL>(e, lane)] = acc[i][j][e];
             }
         STAMP(2);
         lds_barrier();
@@ -597,9 +640,10 @@ __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::T
             if (active)
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) {
-                const int col = (j * Cfg::WAVES_N + wn) * 32 + r;
+                const int col0 = (j * Cfg::WAVES_N + wn) * 32;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) C[(wm * 32 + acc_row32(e, h)) * Cfg::BN + col] = acc[i][j][e];
+                for (int e = 0; e < 16; ++e)
+                    C[(wm * 32 + acc_rpos<ACCL>(e, lane)) * Cfg::BN + col0 + acc_cpos<ACCL>(e, lane)] = acc[i][j][e];
             }
             lds_barrier();  // also orders pass i-2's reads of this buffer before pass i's writes (see above)
             if (active) epi.template run<PassCfg<Cfg::RB, Cfg::BN, Cfg::NT>>((const float *)C, m0 + i * Cfg::RB, n0, rowtab + i * Cfg::RB, coltab);
@@ -615,9 +659,10 @@ __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::T
             if (active)
 #pragma unroll
             for (int i = 0; i < Cfg::TM; ++i) {
-                const int col = (i * Cfg::WAVES_M + wm) * 32 + r;
+                const int col0 = (i * Cfg::WAVES_M + wm) * 32;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) C[(wn * 32 + acc_row32(e, h)) * Cfg::BM + col] = acc[i][j][e];
+                for (int e = 0; e < 16; ++e)
+                    C[(wn * 32 + acc_rpos<ACCL>(e, lane)) * Cfg::BM + col0 + acc_cpos<ACCL>(e, lane)] = acc[i][j][e];
             }
             lds_barrier();
             if (active) epi.template run<PassCfg<Cfg::BM, Cfg::CB, Cfg::NT>>((const float *)C, m0, n0 + j * Cfg::CB, rowtab, coltab + j * Cfg::CB);
@@ -654,7 +699,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_dma_kernel(const E *__restrict__
 #pragma unroll
         for (int j = 0; j < Cfg::TN; ++j) asm volatile("" ::"v"(acc[i][j]));
 #else
-    run_epilogue<Cfg, SWAP, Epi, NSTAGE * (Cfg::BM + Cfg::BN) * 128, decltype(pre)>(acc, smem, epi, m0, n0, true, &pre);
+    run_epilogue<Cfg, SWAP, Epi, NSTAGE * (Cfg::BM + Cfg::BN) * 128, decltype(pre), accl_of<Cfg, E>()>(acc, smem, epi, m0, n0, true, &pre);
 #endif
     STAMP(4);
 #ifdef OCM_GEMM_STAMPS
@@ -678,7 +723,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_kernel(ALoad al, const E *__rest
     STAMP(0);
     gemm_mainloop<Cfg, E, SWAP, KSTEPS>(al, W, ldw, m0, n0, M, N, K, smem, acc, epi.bias);
     STAMP(1);  // prologue + K loop done
-    run_epilogue<Cfg, SWAP, Epi, Cfg::LDS_BYTES, decltype(pre)>(acc, smem, epi, m0, n0, true, &pre);  // STAMP 2: accumulators staged, 3: barrier passed
+    run_epilogue<Cfg, SWAP, Epi, Cfg::LDS_BYTES, decltype(pre), accl_of<Cfg, E>()>(acc, smem, epi, m0, n0, true, &pre);  // STAMP 2: accumulators staged, 3: barrier passed
     STAMP(4);  // epilogue body issued
 #ifdef OCM_GEMM_STAMPS
     __builtin_amdgcn_s_waitcnt(0);

@@ -29,6 +29,10 @@ typedef GemmCfg<128, 128, 2, 2> Cfg128x128;
 // the qkv projection runs the same tile with 8 waves (32x64 MFMA sub-tiles per wave): two waves per SIMD inside
 // one workgroup overlap its heavier scatter epilogue with the other waves' MFMAs (29.0 -> 25.8 us at ViT-S, B=64)
 typedef GemmCfg<128, 128, 2, 4> Cfg128x128q;
+// ... and on v_mfma_f32_16x16x32_bf16 for the split-bf16 LDS-DMA launches of that tile (gemm_core.h: GemmCfg::MF16)
+typedef GemmCfg<128, 128, 2, 4, 1> Cfg128x128q16;
+typedef GemmCfg<128, 128, 2, 2, 1> Cfg128x128m16;  // development A/B (four waves: the tile of forwards of 32 k rows and more)
+typedef GemmCfg<256, 256, 2, 4, 1> Cfg256x256m16;  // ViT-B sizes
 typedef GemmCfg<64, 128, 2, 2> Cfg64x128;
 // the same tile on eight wavefronts (32 x 32 each) for the one-tile-per-call forwards: with ONE workgroup per CU a lone wave per
 // SIMD waits out every LDS read before its MFMAs (850 cycles per K step for 384 of MFMA, tools/stamps_b1.py); two waves per SIMD
@@ -393,6 +397,8 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             case 10: if (N % 64 == 0) return launch_gemm_dma<Cfg64x64, E, 4>(a, K, w, K, M, N, K, epi, s); break;
             case 11: if (N == 384) return launch_gemm_dma<Cfg128x192, E, 3>(a, K, w, K, M, N, K, epi, s); break;
             case 12: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128q, E, 2>(a, K, w, K, M, N, K, epi, s); break;  // 8 waves
+            case 13: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128q16, E, 2>(a, K, w, K, M, N, K, epi, s); break;
+            case 14: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128m16, E, 2>(a, K, w, K, M, N, K, epi, s); break;
             default: break;
         }
 #endif
@@ -407,8 +413,9 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             if (K >= 1024 && N % 64 == 0) return launch_gemm_dma<Cfg64x64, E, 4>(a, K, w, K, M, N, K, epi, s);
             if (N % 128 == 0) return launch_gemm_dma<Cfg64x128w, E, OCM_SMALLM_STAGES>(a, K, w, K, M, N, K, epi, s);
         }
-        if (big_tiles_pay(M, N, K))  // ViT-B at 384^2: 256x256 tiles, one 8-wave workgroup per CU (fc1 1020 -> 944 us)
-            return launch_gemm_dma<Cfg256x256, E, 2>(a, K, w, K, M, N, K, epi, s);
+        if (big_tiles_pay(M, N, K))  // ViT-B at 384^2: 256x256 tiles, one 8-wave workgroup per CU (fc1 1020 -> 944 us), on
+            // v_mfma_f32_16x16x32_bf16 since round 4 (B = 128, alternating runs: fc1 965 -> 870 us, fc2 903 -> 820, proj 281 -> 256)
+            return launch_gemm_dma<Cfg256x256m16, E, 2>(a, K, w, K, M, N, K, epi, s);
         // Narrow outputs (attn.proj / mlp.fc2 of ViT-S: N = 384) with too few rows for 512 tiles of 128 x 128: 128 x 192
         // tiles, one 8-wave workgroup per CU on a three-stage LDS-DMA ring. Per K step 40 KiB of operands for 1152 cycles
         // of MFMA per SIMD (56 KiB for the 64 x 384 full-row tile, 64 KiB for two 64 x 128 tiles): ViT-S/16 at B = 64,
@@ -425,7 +432,7 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             // wide outputs (mlp.fc1): the same tile on eight wavefronts, four per SIMD with two workgroups per CU (58.0 -> 56.2 us
             // in the forward on one box, 53.0 -> 51.8 on another; the N = 384 layers lose on it: fc2 56 -> 62, proj 26 -> 27, and
             // so does mlp.fc1 at 48 k rows: slab sweep 530 -> 533 ms)
-            if (N >= 1024 && M < 32768) return launch_gemm_dma<Cfg128x128q, E, 2>(a, K, w, K, M, N, K, epi, s);
+            if (N >= 1024 && M < 32768) return launch_gemm_dma<Cfg128x128q16, E, 2>(a, K, w, K, M, N, K, epi, s);
             return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
         }
         // Swin-T's narrow stages (N = 96, 192, 288, 576 at 2e5 .. 8e5 rows): tiles that divide N exactly on the LDS-DMA
@@ -484,7 +491,7 @@ __global__ __launch_bounds__(Cfg::NT) void gemm_dma_splitk_kernel(const E *__res
     const auto pre = epi_prefetch<Cfg>(epi, m0, n0, M, N);
     gemm_mainloop_dma<Cfg, E, false, KSTEPS, NSTAGE>(A + (size_t)slice * Kslice, lda, W + (size_t)slice * Kslice, ldw, m0, n0, M,
                                                      N, Kslice, smem, acc, (const float *)nullptr);
-    run_epilogue<Cfg, false, EpiLinear<0, E>, NSTAGE * (Cfg::BM + Cfg::BN) * 128, decltype(pre)>(acc, smem, epi, m0, n0, true,
+    run_epilogue<Cfg, false, EpiLinear<0, E>, NSTAGE * (Cfg::BM + Cfg::BN) * 128, decltype(pre), accl_of<Cfg, E>()>(acc, smem, epi, m0, n0, true,
                                                                                                   &pre);
 }
 
@@ -885,10 +892,10 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_kernel(RowLoader<E> al, const E *
     const auto pre = epi_prefetch<Cfg>(eqk, m0, n0, M, N);
     if (n0 < 2 * D) {  // workgroup-uniform
         gemm_mainloop<Cfg, E, false, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
-        run_epilogue<Cfg, false, EpiQK<E>, Cfg::LDS_BYTES, decltype(pre)>(acc, smem, eqk, m0, n0, true, &pre);
+        run_epilogue<Cfg, false, EpiQK<E>, Cfg::LDS_BYTES, decltype(pre), accl_of<Cfg, E>()>(acc, smem, eqk, m0, n0, true, &pre);
     } else {
         gemm_mainloop<Cfg, E, true, KSTEPS>(al, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
-        run_epilogue<Cfg, true, EpiVt<E>, Cfg::LDS_BYTES, decltype(pre)>(acc, smem, ev, m0, n0, true, &pre);
+        run_epilogue<Cfg, true, EpiVt<E>, Cfg::LDS_BYTES, decltype(pre), accl_of<Cfg, E>()>(acc, smem, ev, m0, n0, true, &pre);
     }
 }
 
@@ -907,10 +914,10 @@ __global__ __launch_bounds__(Cfg::NT) void qkv_dma_kernel(const E *__restrict__ 
     constexpr int RING = NSTAGE * (Cfg::BM + Cfg::BN) * 128;
     if (n0 < 2 * D) {  // workgroup-uniform
         gemm_mainloop_dma<Cfg, E, false, KSTEPS, NSTAGE>(A, K, W, K, m0, n0, M, N, K, smem, acc, eqk.bias);
-        run_epilogue<Cfg, false, EpiQK<E>, RING, decltype(pre)>(acc, smem, eqk, m0, n0, true, &pre);
+        run_epilogue<Cfg, false, EpiQK<E>, RING, decltype(pre), accl_of<Cfg, E>()>(acc, smem, eqk, m0, n0, true, &pre);
     } else {
         gemm_mainloop_dma<Cfg, E, true, KSTEPS, NSTAGE>(A, K, W, K, m0, n0, M, N, K, smem, acc, ev.bias);
-        run_epilogue<Cfg, true, EpiVt<E>, RING, decltype(pre)>(acc, smem, ev, m0, n0, true, &pre);
+        run_epilogue<Cfg, true, EpiVt<E>, RING, decltype(pre), accl_of<Cfg, E>()>(acc, smem, ev, m0, n0, true, &pre);
     }
 }
 
@@ -990,6 +997,7 @@ hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E
                 case 2: return launch_qkv_dma<Cfg128x128q, E, 2>(a, w, M, D, eqk, ev, s);
                 case 3: return launch_qkv_dma<Cfg64x128, E, 2>(a, w, M, D, eqk, ev, s);
                 case 4: if (D % 256 == 0) return launch_qkv_dma<Cfg256x256, E, 2>(a, w, M, D, eqk, ev, s); break;
+                case 5: return launch_qkv_dma<Cfg128x128q16, E, 2>(a, w, M, D, eqk, ev, s);
                 default: break;
             }
 #endif
@@ -997,11 +1005,13 @@ hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E
                 // few rows (one tile per call): the DMA loop's shorter prologue shows (B = 1 forward 1.03 -> 1.01 ms)
                 if (M <= OCM_SMALLM_ROWS) return launch_qkv_dma<Cfg64x128w, E, OCM_SMALLM_STAGES>(a, w, M, D, eqk, ev, s);
                 // ViT-B sizes: 256 x 256 tiles halve the bytes through L2 (384^2 B = 128: 755 -> 715 us per launch)
-                if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_dma<Cfg256x256, E, 2>(a, w, M, D, eqk, ev, s);
+                // (on v_mfma_f32_16x16x32_bf16 since round 4: 717 -> 670 us)
+                if (D % 256 == 0 && big_tiles_pay(M, 3 * D, D)) return launch_qkv_dma<Cfg256x256m16, E, 2>(a, w, M, D, eqk, ev, s);
                 // the 8-wave 128 x 128 tile on the LDS-DMA loop (ViT-S/16 B = 64: 46.6 -> 41.8 us per launch, +2 % end
                 // to end; ViT-B/16 384^2 B = 128: 805 -> 759 us; alternating runs on one box). The 4-wave form of the
                 // same tile (variant 1) measures like the register-staged kernel.
-                if (t128 >= 512) return launch_qkv_dma<Cfg128x128q, E, 2>(a, w, M, D, eqk, ev, s);
+                // ... on v_mfma_f32_16x16x32_bf16 (43.1 -> 41.6 us; GemmCfg::MF16)
+                if (t128 >= 512) return launch_qkv_dma<Cfg128x128q16, E, 2>(a, w, M, D, eqk, ev, s);
             }
         }
     }

@@ -1908,7 +1908,8 @@ hipError_t launch_attention_probs(int prec, const void *q, const void *k, const 
     const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
     // split-bf16 kernels: key chunks in grid.z until there are ~512 workgroups (a one-tile call is 12 .. 114 otherwise)
     const int wgs = (int)(grid.x * grid.y), ktiles = qtiles;
-    const int nz = wgs >= 256 ? 1 : min(ktiles, min(16, (512 + wgs - 1) / wgs));
+    int nz = wgs >= 256 ? 1 : min(ktiles, min(16, (512 + wgs - 1) / wgs));
+    if (OCM_KNOB(2) > 0) nz = min(ktiles, OCM_KNOB(2));  // development A/B
     const dim3 gridz(grid.x, grid.y, nz);
     if (head_dim == 128 && prec == 2) {
         attn_probs_x3_kernel<128><<<gridz, block, 0, s>>>((const char *)q, (const char *)k, lse2, attn, n_tokens, n_pad,

@@ -288,8 +288,11 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
     const int pc = h->prec, ws = c.window_size;
     const float eps = c.ln_eps;
     int H = c.image_size / 4;
-    HIP_TRY(launch_swin_embed(pixel_values, h->ptr<float>(h->emb_w), h->ptr<float>(h->emb_b), h->ptr<float>(h->emb_g),
-                              h->ptr<float>(h->emb_be), w.x, batch, c.num_channels, c.image_size, c.embed_dim, 1e-5f, s));
+    {
+        PROF(OCM_K_PATCH, s);
+        HIP_TRY(launch_swin_embed(pixel_values, h->ptr<float>(h->emb_w), h->ptr<float>(h->emb_b), h->ptr<float>(h->emb_g),
+                                  h->ptr<float>(h->emb_be), w.x, batch, c.num_channels, c.image_size, c.embed_dim, 1e-5f, s));
+    }
     float *x = w.x, *xo = w.x2;
     for (int st = 0; st < c.num_stages; ++st) {
         const int C = h->chans(st), heads = c.num_heads[st], M = (int)(c.mlp_ratio * C);
@@ -301,33 +304,54 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
         for (size_t b = 0; b < h->stages[st].layers.size(); ++b) {
             const LayerP &lp = h->stages[st].layers[b];
             const int shift = (b % 2 == 1 && H > ws) ? ws / 2 : 0;  // set_shift_and_window_size :576-582
+            // kernel classes for ocm_prof_begin / ocm_prof_end (tools/bench_swin.py): LayerNorm kernels -> layernorm; the q|k|v
+            // projection (fused with layernorm_before or not) -> qkv_gemm; window attention -> attention; attention.output.dense
+            // and the patch-merging reduction -> proj_gemm; mlp.fc1 (and the fused LayerNorm + MLP kernel) -> fc1_gemm; mlp.fc2 -> fc2_gemm
             if (h->fuse_mlp && swin_lnqkv_fused_supported(pc, C)) {  // narrow stages: no normalised copy of x in HBM
+                PROF(OCM_K_QKV, s);
                 HIP_TRY(launch_swin_lnqkv(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), h->ptr<char>(lp.wqkv),
                                           h->ptr<float>(lp.bqkv), w.qkv, T, C, eps, s));
             } else {
-                HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), w.xn, T, C, Kc, eps,
-                                       false, 0, 0, s));
+                {
+                    PROF(OCM_K_LN, s);
+                    HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), w.xn, T, C, Kc, eps,
+                                           false, 0, 0, s));
+                }
+                PROF(OCM_K_QKV, s);
                 HIP_TRY(swin_linear(pc, w.xn, Kc, h->ptr<char>(lp.wqkv), h->ptr<float>(lp.bqkv), nullptr, w.qkv, 3 * C,
                                          (int)T, 3 * C, Kc, OCM_EPI_BIAS_BF16, s));
             }
-            HIP_TRY(launch_swin_window_attention(pc, w.qkv, 3 * C, w.ctx, Kc, h->ptr<float>(lp.bias_perm),
-                                                 h->ptr<float>(lp.bias_dense), batch, H, H, ws, shift, heads, s));
-            HIP_TRY(swin_linear(pc, w.ctx, Kc, h->ptr<char>(lp.wo), h->ptr<float>(lp.bo), x, x, C, (int)T, C, Kc,
-                                     OCM_EPI_BIAS_RESID_F32, s));
+            {
+                PROF(OCM_K_ATTN, s);
+                HIP_TRY(launch_swin_window_attention(pc, w.qkv, 3 * C, w.ctx, Kc, h->ptr<float>(lp.bias_perm),
+                                                     h->ptr<float>(lp.bias_dense), batch, H, H, ws, shift, heads, s));
+            }
+            {
+                PROF(OCM_K_PROJ, s);
+                HIP_TRY(swin_linear(pc, w.ctx, Kc, h->ptr<char>(lp.wo), h->ptr<float>(lp.bo), x, x, C, (int)T, C, Kc,
+                                         OCM_EPI_BIAS_RESID_F32, s));
+            }
             if (h->fuse_mlp && swin_mlp_fused_supported(pc, C, M)) {  // narrow stages: the hidden activations stay on chip
+                PROF(OCM_K_FC1, s);
                 HIP_TRY(launch_swin_mlp(pc, x, h->ptr<float>(lp.ln2_g), h->ptr<float>(lp.ln2_b), h->ptr<char>(lp.w1),
                                         h->ptr<float>(lp.b1), h->ptr<char>(lp.w2), h->ptr<float>(lp.b2), T, C, M, eps, s));
                 continue;
             }
             if (h->fuse_mlp && swin_lnqkv_fused_supported(pc, C)) {  // C = 192: layernorm_after + fc1 + GELU in one kernel
+                PROF(OCM_K_FC1, s);
                 HIP_TRY(launch_swin_lnlinear(pc, x, h->ptr<float>(lp.ln2_g), h->ptr<float>(lp.ln2_b), h->ptr<char>(lp.w1),
                                              h->ptr<float>(lp.b1), w.hid, T, C, M, true, eps, s));
             } else {
-                HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln2_g), h->ptr<float>(lp.ln2_b), w.xn, T, C, Kc, eps,
-                                       false, 0, 0, s));
+                {
+                    PROF(OCM_K_LN, s);
+                    HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln2_g), h->ptr<float>(lp.ln2_b), w.xn, T, C, Kc, eps,
+                                           false, 0, 0, s));
+                }
+                PROF(OCM_K_FC1, s);
                 HIP_TRY(swin_linear(pc, w.xn, Kc, h->ptr<char>(lp.w1), h->ptr<float>(lp.b1), nullptr, w.hid, Km, (int)T, M,
                                          Kc, OCM_EPI_BIAS_GELU_BF16, s));
             }
+            PROF(OCM_K_FC2, s);
             HIP_TRY(swin_linear(pc, w.hid, Km, h->ptr<char>(lp.w2), h->ptr<float>(lp.b2), x, x, C, (int)T, C, Km,
                                      OCM_EPI_BIAS_RESID_F32, s));
         }
@@ -335,10 +359,16 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
             const StageP &sp = h->stages[st];
             const size_t T4 = T / 4;
             const int K4 = h->Kp(4 * C);
-            HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(sp.red_g), h->ptr<float>(sp.red_b), w.xn, T4, 4 * C, K4, 1e-5f, true,
-                                   H, H, s));
-            HIP_TRY(swin_linear(pc, w.xn, K4, h->ptr<char>(sp.red_w), nullptr, nullptr, xo, 2 * C, (int)T4, 2 * C, K4,
-                                     OCM_EPI_BIAS_F32, s));
+            {
+                PROF(OCM_K_LN, s);
+                HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(sp.red_g), h->ptr<float>(sp.red_b), w.xn, T4, 4 * C, K4, 1e-5f, true,
+                                       H, H, s));
+            }
+            {
+                PROF(OCM_K_PROJ, s);
+                HIP_TRY(swin_linear(pc, w.xn, K4, h->ptr<char>(sp.red_w), nullptr, nullptr, xo, 2 * C, (int)T4, 2 * C, K4,
+                                         OCM_EPI_BIAS_F32, s));
+            }
             float *t = x;
             x = xo;
             xo = t;
@@ -346,6 +376,7 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
         }
     }
     const int Cl = h->chans(c.num_stages - 1);
+    PROF(OCM_K_LN, s);
     HIP_TRY(launch_swin_pool_head(x, h->ptr<float>(h->fin_g), h->ptr<float>(h->fin_b), h->ptr<float>(h->cls_w),
                                   h->ptr<float>(h->cls_b), logits, pooled, last_hidden, batch, H * H, Cl, c.num_labels, eps,
                                   s));
