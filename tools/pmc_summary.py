@@ -8,7 +8,7 @@ from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
 for path in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(path)):
-        name = row["Kernel_Name"][:70]
+        name = row["Kernel_Name"][:96]
         acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for name, d in acc.items():
     print(name)

@@ -12,19 +12,20 @@ import sys
 # kernel class -> leading text of the kernel name (after "void "), per precision mode
 CLASSES = {
     "bf16x3": {
-        "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 4>, sp32, false, 12,",  # eight-wave tile since the end of round 3
+        # round 4: GemmCfg carries the MFMA shape as its fifth argument (1 = v_mfma_f32_16x16x32_bf16: fc1 / qkv)
+        "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 4, 1>, sp32, false, 12,",
         # round 3: LayerNorm folded into its consumer -> attn.proj / mlp.fc2 on 128 x 192 LDS-DMA tiles (x, split(x), row sums)
-        "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2>, sp32, false, 48,",
-        "proj_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2>, sp32, false, 12,",
-        "qkv_gemm": "qkv_dma_kernel<GemmCfg<128, 128, 2, 4>, sp32, 12, 2>",
-        "attention": "attn_fwd_x3_dma_kernel<true, 4, 3,",
-        "patch_embed": "gemm_kernel<GemmCfg<64, 128, 2, 2>, sp32, false, 24, PatchLoader<",
+        "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2, 0>, sp32, false, 48,",
+        "proj_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2, 0>, sp32, false, 12,",
+        "qkv_gemm": "qkv_dma_kernel<GemmCfg<128, 128, 2, 4, 1>, sp32, 12, 2>",
+        "attention": "attn_fwd_x3_pp_kernel<true>",  # round 4: the software-pipelined kernel up to 1 024 tokens
+        "patch_embed": "gemm_kernel<GemmCfg<64, 128, 2, 2, 0>, sp32, false, 24, PatchLoader<",
     },
     # config 4 (ViT-S/8 slab sweep, 20-21 windows of 2305 tokens per launch): summaries of tools/sweep_slab.py runs
     "slab_bf16x3": {
         "attention": "attn_fwd_x3_dma_kernel<true, 8, 2,",
-        "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2>, sp32, false, 48, 3, EpiLinear<1",  # 128 x 192 tiles, LayerNorm kernels at this size
-        "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2>, sp32, false, 12, 2, EpiL",
+        "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2, 0>, sp32, false, 48, 3, EpiLinear<1",  # 128 x 192 tiles, LayerNorm kernels at this size
+        "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 2, 0>, sp32, false, 12, 2, EpiL",
     },
 }
 

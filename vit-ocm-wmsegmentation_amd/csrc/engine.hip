@@ -334,6 +334,8 @@ struct Workspace {  // E = bf16 (OCM_PREC_BF16) or float (OCM_PREC_FP32)
     float *part;  // [OCM_SPLITK][T][D] fp32 partial sums of mlp.fc2 when it runs as split-K (T <= OCM_SPLITK_MAX_ROWS), else null
     float *stats; // [2][T][D/64][2] row sums (sum x, sum x^2 per 64-column slot) of the residual stream at the LayerNorm site being
                   // produced / consumed (folded LayerNorm: even sites in half 0, odd sites in half 1)
+    float *shift; // [2][T] the per-row constants the pairs and sums of that site are centred by (launch.h: row centring), same halves
+    float *tok_shift;  // [n] the first site's per-token constants (mean of the positional row + mean of the patch-embedding bias)
     size_t bytes;
 };
 
@@ -351,6 +353,8 @@ static Workspace carve(const ocm_vit *h, int batch, int n, char *base) {
     w.xn = take(T * h->D * e);
     w.lse = (float *)take(BH * n * 4);
     w.stats = h->can_fold() ? (float *)take(2 * T * (size_t)(h->D / 64) * 8) : nullptr;
+    w.shift = h->can_fold() ? (float *)take(2 * T * 4) : nullptr;
+    w.tok_shift = h->can_fold() ? (float *)take((size_t)n * 4) : nullptr;
     w.part = (h->prec == 2 && T <= (size_t)OCM_SPLITK_MAX_ROWS) ? (float *)take((size_t)OCM_SPLITK * T * h->D * 4) : nullptr;
     w.kpart_bytes = attention_ksplit_bytes(h->prec, batch, n, h->H, h->hd);
     w.kpart = w.kpart_bytes ? (float *)take(w.kpart_bytes) : nullptr;
@@ -514,6 +518,10 @@ static int run_block_folded(const ocm_vit *h, int i, const Workspace &w, float *
     StatsOut so_mid, so_out;
     so_mid.xs = w.xn, so_mid.stats = st_mid;
     so_out.xs = w.xn, so_out.stats = st_out;
+    // row centring (launch.h): each site's pairs and sums are those of x minus the row's mean at the site before it
+    float *sh_in = w.shift, *sh_mid = w.shift + T;
+    so_mid.shift = sh_mid, so_mid.prev_stats = st_in, so_mid.prev_shift = sh_in;
+    so_out.shift = sh_in, so_out.prev_stats = st_mid, so_out.prev_shift = sh_mid;
     so_out.part = w.part;  // few rows: mlp.fc2 as split-K (launch.h)
     { PROF(OCM_K_PROJ, s); HIP_TRY(launch_linear(pc, w.ctx, h->ptr<char>(bp.proj_w), h->ptr<float>(bp.proj_b), x, x, T, D, D, OCM_EPI_BIAS_RESID_F32, s, LnFold(), so_mid)); }
     { PROF(OCM_K_FC1, s); HIP_TRY(launch_linear(pc, w.xn, h->ptr<char>(bp.fc1_wf), nullptr, nullptr, w.hid, T, h->M, D, OCM_EPI_BIAS_GELU_BF16, s, ln2)); }
@@ -535,7 +543,7 @@ static int check_tiles(const ocm_vit *h, const ocm_vit_io *io, int *n_out) {
 }
 
 static int run_prepare(const ocm_vit *h, const ocm_vit_io *io, float *x, int n, hipStream_t s, void *xs = nullptr,
-                       float *stats = nullptr) {
+                       float *stats = nullptr, float *shift = nullptr, float *tok_shift = nullptr) {
     PatchArgs pa{io->image, io->img_stride_b, io->img_stride_c, io->img_stride_y, io->tile_origins,
                  io->batch, io->tile_h / h->p, io->tile_w / h->p, h->p, h->C};
     if (io->patch_mask) {
@@ -545,8 +553,10 @@ static int run_prepare(const ocm_vit *h, const ocm_vit_io *io, float *x, int n, 
     }
     StatsOut so;
     so.xs = xs, so.stats = stats;
-    if (stats)  // folded first LayerNorm: the token rows also leave as split pairs with their row sums
-        HIP_TRY(launch_cls_rows_stats(h->ptr<float>(h->cls), io->pos_embed, x, xs, stats, io->batch, n, h->D, s));
+    so.shift = shift, so.tok_shift = tok_shift;
+    if (stats)  // folded first LayerNorm: the token rows also leave as split pairs with their row sums (and the rows' centring constants)
+        HIP_TRY(launch_cls_rows_stats(h->ptr<float>(h->cls), io->pos_embed, x, xs, stats, io->batch, n, h->D, s, shift, tok_shift,
+                                      h->ptr<float>(h->pe_b)));
     else
         HIP_TRY(launch_cls_rows(h->ptr<float>(h->cls), io->pos_embed, x, io->batch, n, h->D, s));
     PROF(OCM_K_PATCH, s);
@@ -603,7 +613,7 @@ static int enqueue_forward(ocm_vit *h, const ocm_vit_io *io, int n, hipStream_t 
     const long t128 = (long)((T + 127) / 128) * (h->D / 128);
     const bool fold = h->folding() && (h->opt[OCM_OPT_FOLD_LN] == 2 || t128 < 512);
     if (fold) {
-        if ((rc = run_prepare(h, io, w.x, n, s, w.xn, w.stats))) return rc;
+        if ((rc = run_prepare(h, io, w.x, n, s, w.xn, w.stats, w.shift, w.tok_shift))) return rc;
     } else if ((rc = run_prepare(h, io, w.x, n, s))) return rc;
     bool xn_ready = false;  // w.xn holds the next block's norm1(x) (fused into the previous fc2)
     for (int i = 0; i < L; ++i) {

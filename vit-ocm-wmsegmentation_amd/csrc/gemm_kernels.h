@@ -240,6 +240,9 @@ struct EpiResidStats {
     float *stats;
     int M, N;
     int wt = 3;  // bit 0: x, bit 1: xs with write-through stores
+    // row centring (launch.h): the pairs and the sums are those of x - shift[row], shift[row] = the row's mean at the previous site
+    float *shift = nullptr;
+    const float *prev_stats = nullptr, *prev_shift = nullptr;
     __device__ __forceinline__ static void st16(void *p, const f32x4 &v, bool through) {
         if (through)
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
@@ -262,6 +265,17 @@ struct EpiResidStats {
                 v[i][0] = *(const f32x4 *)(resid + mo + n0 + sub * 8 + i * 64);
                 v[i][1] = *(const f32x4 *)(resid + mo + n0 + sub * 8 + i * 64 + 4);
             }
+            float sh = 0.f;
+            if (shift) {  // the eight lanes of the row add the previous site's slots (fixed tree: the same bits in every tile)
+                const int nslot = N >> 6;
+                float ps = 0.f;
+                if (prev_stats)
+                    for (int i = sub; i < nslot; i += 8) ps += prev_stats[((int64_t)min(m, M - 1) * nslot + i) * 2];
+#pragma unroll
+                for (int o = 4; o > 0; o >>= 1) ps += __shfl_xor(ps, o, 64);
+                sh = (prev_shift ? prev_shift[min(m, M - 1)] : 0.f) + ps / (float)N;
+                if (ok && n0 == 0 && sub == 0) shift[m] = sh;
+            }
             float s1 = 0.f, s2 = 0.f;
             char *rowp = (char *)xs + mo * (int)sizeof(OE);
 #pragma unroll
@@ -273,6 +287,10 @@ struct EpiResidStats {
                 if (ok) {
                     st16(x + mo + n, v[i][0], wt & 1);
                     st16(x + mo + n + 4, v[i][1], wt & 1);
+                }
+                v[i][0] -= sh;  // from here on the centred row: pairs and sums
+                v[i][1] -= sh;
+                if (ok) {
                     if constexpr (Elem<OE>::MODE == 2) {
                         bf16x8 hi, lo;
                         split8(v[i][0], v[i][1], hi, lo);
@@ -507,7 +525,7 @@ static hipError_t launch_linear_splitk(const E *a, const E *w, const float *bias
     const int tiles = ((M + Cfg::BM - 1) / Cfg::BM) * (N / Cfg::BN);
     kern<<<dim3(tiles, OCM_SPLITK), dim3(Cfg::NT), LDS, s>>>(a, K, w, K, M, N, K / OCM_SPLITK, so.part);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
-    return launch_splitk_finish(so.part, OCM_SPLITK, bias, resid, x, so.xs, so.stats, M, N, s);
+    return launch_splitk_finish(so.part, OCM_SPLITK, bias, resid, x, so.xs, so.stats, M, N, s, so);
 }
 
 // epilogue 4 (internal): x = resid + acc + bias in place, plus split pairs and row sums of x (StatsOut)
@@ -524,6 +542,7 @@ hipError_t launch_linear_e(const E *a, const E *w, const float *bias, const floa
             if (so.stats) {
                 if (N % 64) return hipErrorInvalidValue;
                 EpiResidStats<E> epi{bias, resid, (float *)out, so.xs, so.stats, M, N};
+                epi.shift = so.shift, epi.prev_stats = so.prev_stats, epi.prev_shift = so.prev_shift;
                 epi.wt = OCM_KNOB(5) ? OCM_KNOB(5) - 1 : 0;  // development knob 5: 1 + write-through mask. Plain stores ship: x written
                 // through costs the producers 3 us per launch and buys the consumers nothing (in-forward A/B)
                 return launch_linear_epi<1, E>(a, w, epi, M, N, K, s);
@@ -1131,9 +1150,12 @@ struct EpiPatch {
             }
             v += *(const f32x4 *)(pos + (int64_t)(1 + t) * D + nc);
             const int64_t xrow = (int64_t)b * ntok + 1 + t;
+            const float sh = so.tok_shift ? so.tok_shift[1 + t] : 0.f;  // row centring (launch.h): a per-token constant here
             float s1 = 0.f, s2 = 0.f;
             if (ok) {
                 *(f32x4 *)(x + xrow * D + n) = v;
+                if (so.shift && n0 == 0 && sl == 0) so.shift[xrow] = sh;
+                v -= sh;
                 bf16x4 hi, lo;
                 split4(v, hi, lo);
                 char *g = (char *)so.xs + xrow * D * 4 + sp_off(n);

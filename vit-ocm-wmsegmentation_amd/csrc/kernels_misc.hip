@@ -308,20 +308,41 @@ hipError_t launch_cls_rows(const float *cls, const float *pos, float *x, int bat
 // image; the patch rows come from the patch-embedding epilogue).
 __global__ __launch_bounds__(64) void cls_rows_stats_kernel(const float *__restrict__ cls, const float *__restrict__ pos,
                                                             float *__restrict__ x, char *__restrict__ xs,
-                                                            float *__restrict__ stats, int n_tokens, int dim) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+                                                            float *__restrict__ stats, int n_tokens, int dim, int batch,
+                                                            float *__restrict__ shift, float *__restrict__ tok_shift,
+                                                            const float *__restrict__ pe_bias) {
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x >= batch) {  // blocks batch .. batch + n_tokens - 1: the patch rows' centring constants (launch.h)
+        const int n = (int)blockIdx.x - batch;
+        float sm = 0.f;
+        for (int c = lane; c < dim; c += 64) sm += pos[(size_t)n * dim + c] + (pe_bias ? pe_bias[c] : 0.f);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+        if (lane == 0) tok_shift[n] = sm / (float)dim;
+        return;
+    }
+    const int b = blockIdx.x;
     const size_t row = (size_t)b * n_tokens;
+    float sh = 0.f;
+    if (shift) {  // the cls row's exact mean
+        for (int c = lane; c < dim; c += 64) sh += cls[c] + pos[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sh += __shfl_xor(sh, o, 64);
+        sh /= (float)dim;
+        if (lane == 0) shift[row] = sh;
+    }
     float s1 = 0.f, s2 = 0.f;
     for (int c = lane; c < dim; c += 64) {
         const float v = cls[c] + pos[c];
         x[row * dim + c] = v;
+        const float vc = v - sh;
         bf16 hi, lo;
-        split1(v, hi, lo);
+        split1(vc, hi, lo);
         char *g = xs + row * dim * 4 + sp_off(c);
         *(bf16 *)g = hi;
         *(bf16 *)(g + 64) = lo;
-        s1 += v;
-        s2 = fmaf(v, v, s2);
+        s1 += vc;
+        s2 = fmaf(vc, vc, s2);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -336,8 +357,10 @@ __global__ __launch_bounds__(64) void cls_rows_stats_kernel(const float *__restr
 }
 
 hipError_t launch_cls_rows_stats(const float *cls, const float *pos, float *x, void *xs, float *stats, int batch,
-                                 int n_tokens, int dim, hipStream_t s) {
-    cls_rows_stats_kernel<<<dim3(batch), dim3(64), 0, s>>>(cls, pos, x, (char *)xs, stats, n_tokens, dim);
+                                 int n_tokens, int dim, hipStream_t s, float *shift, float *tok_shift, const float *pe_bias) {
+    const int extra = (shift && tok_shift) ? n_tokens : 0;
+    cls_rows_stats_kernel<<<dim3(batch + extra), dim3(64), 0, s>>>(cls, pos, x, (char *)xs, stats, n_tokens, dim, batch,
+                                                                   extra ? shift : nullptr, tok_shift, pe_bias);
     return hipGetLastError();
 }
 
@@ -347,16 +370,30 @@ hipError_t launch_cls_rows_stats(const float *cls, const float *pos, float *x, v
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float *__restrict__ part, int slices,
                                                             const float *__restrict__ bias, const float *resid,
                                                             float *x, char *__restrict__ xs, float *__restrict__ stats,
-                                                            int M, int N) {
+                                                            int M, int N, float *__restrict__ shift,
+                                                            const float *__restrict__ prev_stats,
+                                                            const float *__restrict__ prev_shift) {
     const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const size_t row = (size_t)m * N, slice = (size_t)M * N;
+    const int nslot = N >> 6;
+    float sh = 0.f;
+    if (shift) {  // the row's mean at the previous LayerNorm site (launch.h: row centring)
+        float ps = 0.f;
+        if (prev_stats)
+            for (int i = lane; i < nslot; i += 64) ps += prev_stats[((size_t)m * nslot + i) * 2];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o, 64);
+        sh = (prev_shift ? prev_shift[m] : 0.f) + ps / (float)N;
+        if (lane == 0) shift[m] = sh;
+    }
     float s1 = 0.f, s2 = 0.f;
     for (int c = lane * 4; c < N; c += 256) {
         f32x4 v = *(const f32x4 *)(resid + row + c);
         if (bias) v += *(const f32x4 *)(bias + c);
         for (int k = 0; k < slices; ++k) v += *(const f32x4 *)(part + k * slice + row + c);
         *(f32x4 *)(x + row + c) = v;
+        v -= sh;
         if (xs) {
             bf16x4 hi, lo;
             split4(v, hi, lo);
@@ -376,7 +413,6 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float *__restr
         s1 += __shfl_xor(s1, o, 64);
         s2 += __shfl_xor(s2, o, 64);
     }
-    const int nslot = N >> 6;
     if (lane < nslot) {
         stats[((size_t)m * nslot + lane) * 2] = lane ? 0.f : s1;
         stats[((size_t)m * nslot + lane) * 2 + 1] = lane ? 0.f : s2;
@@ -384,9 +420,10 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float *__restr
 }
 
 hipError_t launch_splitk_finish(const float *part, int slices, const float *bias, const float *resid, float *x, void *xs,
-                                float *stats, int M, int N, hipStream_t s) {
+                                float *stats, int M, int N, hipStream_t s, const StatsOut &so) {
     if (N % 4 || (stats && (N % 64 || N / 64 > 64)) || slices <= 0 || M <= 0) return hipErrorInvalidValue;
-    splitk_finish_kernel<<<dim3((M + 3) / 4), dim3(256), 0, s>>>(part, slices, bias, resid, x, (char *)xs, stats, M, N);
+    splitk_finish_kernel<<<dim3((M + 3) / 4), dim3(256), 0, s>>>(part, slices, bias, resid, x, (char *)xs, stats, M, N,
+                                                                 stats ? so.shift : nullptr, so.prev_stats, so.prev_shift);
     return hipGetLastError();
 }
 

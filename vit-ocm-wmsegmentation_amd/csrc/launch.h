@@ -31,10 +31,20 @@ struct LnFold {
     float inv_dim = 0.f, eps = 0.f;
     int nslot = 0;  // dim / 64
 };
+// Row centring (round 4). LayerNorm does not see a constant added to a whole row, but the split-bf16 rounding of the operand
+// does: a row whose mean is 30 standard deviations from zero carries 30 x the rounding error of its centred self into the
+// consumer's products (measured: attention L_inf 5e-5 -> 5e-3 on such rows). So the pairs a producer writes are those of
+// x - s[row], and the sums those of x - s[row], with s[row] a per-row constant that every column tile of the row can know without
+// talking to the others: the row's mean AT THE PREVIOUS LayerNorm site (previous shift + previous sums / N; the residual stream
+// moves little between sites) — at the first site a per-token constant (mean of the positional row + mean of the bias; the
+// cls row: its exact mean). The consumer is unchanged: LN(x - s) = LN(x). x itself is stored unshifted.
 // What a producing epilogue (x = resid + acc) writes besides x when the next LayerNorm is folded
 struct StatsOut {
-    void *xs = nullptr;      // [rows][N] split pairs of x, or null
-    float *stats = nullptr;  // [rows][N / 64][2]
+    void *xs = nullptr;      // [rows][N] split pairs of x - shift[row], or null
+    float *stats = nullptr;  // [rows][N / 64][2] sums of x - shift[row]
+    float *shift = nullptr;  // [rows] out: the constant subtracted from each row (null: nothing is subtracted)
+    const float *prev_stats = nullptr, *prev_shift = nullptr;  // the previous site's sums and shifts of the same rows, or
+    const float *tok_shift = nullptr;                          // (first site) [n_tokens] per-token constants
     // Few rows and a long contraction (mlp.fc2 of a one-tile-per-call forward: M = 197, K = 1536 on 24 workgroups): the K range
     // is cut into OCM_SPLITK slices, one workgroup per (tile, slice) writes fp32 partial sums here ([slices][M][N]) and a row
     // kernel adds them in slice order with bias and residual (and produces xs / stats). Null: never split.
@@ -43,9 +53,12 @@ struct StatsOut {
 constexpr int OCM_SPLITK = 4, OCM_SPLITK_MAX_ROWS = 512;  // at 2305 rows (one ViT-S/8 window) the split form measures the same as the plain kernel
 // x = resid + bias + sum over slices of part[slice] (fixed order); optionally split pairs and row sums of x
 hipError_t launch_splitk_finish(const float *part, int slices, const float *bias, const float *resid, float *x, void *xs,
-                                float *stats, int M, int N, hipStream_t s);
+                                float *stats, int M, int N, hipStream_t s, const StatsOut &so = StatsOut());
+// + (shift / tok_shift non-null) the cls rows' exact means into shift[b * n_tokens] and the per-token constants
+// tok_shift[n] = mean(pos[n]) + mean(bias) of the patch rows, which the patch-embedding epilogue subtracts
 hipError_t launch_cls_rows_stats(const float *cls, const float *pos, float *x, void *xs, float *stats, int batch,
-                                 int n_tokens, int dim, hipStream_t s);
+                                 int n_tokens, int dim, hipStream_t s, float *shift = nullptr, float *tok_shift = nullptr,
+                                 const float *pe_bias = nullptr);
 hipError_t launch_fold_ln(const float *W, const float *gamma, const float *beta, const float *bias, void *Wf, float *cvec,
                           float *dvec, int N, int K, hipStream_t s);
 
