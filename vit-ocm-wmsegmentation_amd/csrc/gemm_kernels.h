@@ -450,7 +450,10 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             // wide outputs (mlp.fc1): the same tile on eight wavefronts, four per SIMD with two workgroups per CU (58.0 -> 56.2 us
             // in the forward on one box, 53.0 -> 51.8 on another; the N = 384 layers lose on it: fc2 56 -> 62, proj 26 -> 27, and
             // so does mlp.fc1 at 48 k rows: slab sweep 530 -> 533 ms)
-            if (N >= 1024 && M < 32768) return launch_gemm_dma<Cfg128x128q16, E, 2>(a, K, w, K, M, N, K, epi, s);
+            // (round 4, on the 16 x 16 MFMA shape: at 48 k rows too — slab sweep 541.8 -> 538.7 ms against the four-wave tile, which
+            // on the 32 x 32 shape had been the faster one there; knob 0 = 17: the four-wave tile on the 16 x 16 shape, 542.9 ms)
+            if (N >= 1024 && OCM_KNOB(0) != 17) return launch_gemm_dma<Cfg128x128q16, E, 2>(a, K, w, K, M, N, K, epi, s);
+            if (OCM_KNOB(0) == 17) return launch_gemm_dma<Cfg128x128m16, E, 2>(a, K, w, K, M, N, K, epi, s);
             return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
         }
         // Swin-T's narrow stages (N = 96, 192, 288, 576 at 2e5 .. 8e5 rows): tiles that divide N exactly on the LDS-DMA
