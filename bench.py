@@ -249,6 +249,10 @@ def main():
     import vit_ocm_wmsegmentation_amd.dino.vision_transformer as vits
     from vit_ocm_wmsegmentation_amd import _lib, synth
     lib = _lib.load()
+    # CPU-side torch work in this process (synthetic weights, the parity probes) on a few threads only: a full-width OpenMP team
+    # keeps spinning after every parallel region and competes with the thread that launches kernels. cpu_baseline() sets the
+    # full core count for itself at the very end.
+    torch.set_num_threads(max(1, min(4, host_cores() // max(1, world))))
 
     D, L, H = synth.ARCHS[args.arch]
     B, S, p = args.batch, args.size, args.patch
@@ -361,6 +365,37 @@ def main():
     if rank != 0:
         return
 
+    # the single-bf16 fast mode next to the headline (rank 0, same batch, no collective): what the extra precision costs.
+    # Timed BEFORE the CPU oracle runs below: their OpenMP workers keep spinning for a while after each parallel region and
+    # take the launching thread's core (the leg read 1.5 / 3.0 / 4.4 ms per step on different boxes when it ran after them,
+    # with the same 35 us fc1 launches under the events)
+    fast = ob_pick = None
+    if args.precision == "bf16x3" and default_workload:
+        model.load_state_dict(synth.synth_arch_state_dict(args.arch, p, seed=0, variant="peaked"))
+        model.set_precision("bf16")
+        ob_pick = model._run(x, flags=flags)["attn"][0][sorted({0, B // 2, B - 1})].cpu()
+        for _ in range(3):
+            model._run(x, flags=flags)
+        torch.cuda.synchronize()
+        _lib.check(lib.ocm_prof_begin(1 << _lib.KERNEL_CLASSES.index("fc1_gemm"), args.steps * L + 8))
+        tb = time.perf_counter()
+        for _ in range(args.steps):
+            model._run(x, flags=flags)
+        torch.cuda.synchronize()
+        dtb = time.perf_counter() - tb
+        _lib.check(lib.ocm_prof_end(ms, cnt))
+        i1 = _lib.KERNEL_CLASSES.index("fc1_gemm")
+        fc1_s = ms[i1] / max(cnt[i1], 1) * 1e-3
+        fast = {"dtype": "bf16", "value": round(B * args.steps / dtb, 1), "unit": "tiles/s (this rank)",
+                "ms_per_step": round(dtb / args.steps * 1e3, 4), "attn_linf_peaked_weights": None,
+                "note": "single bf16 MFMA operands: ~1.75x the throughput, but 4-8e-2 off the reference on peaked (trained-like) "
+                        "attention, 40-80x the north star's 1e-3 -> not the headline",
+                "roofline": {"bound": "mfma", "kernel": "fc1_gemm", "achieved": round(cf["fc1_gemm"] / fc1_s / 1e12, 2),
+                             "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(cf["fc1_gemm"] / fc1_s / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
+                             "avg_launch_us": round(fc1_s * 1e6, 2)}}
+        model.set_precision(args.precision)
+
     # parity of what was just timed: attention-map L_inf vs the CPU oracle on the FIRST, MIDDLE and LAST tile of the bench
     # batch (a remap or batch-stride slip on later images must show), for the random-init weights of the timed run and for
     # the sharp (qkv x4) and peaked (attention max 0.8-0.9, what a trained checkpoint looks like: qkv x8 on ViT-S/16, the
@@ -381,6 +416,10 @@ def main():
         linf_by_set[variant] = {"linf": float((got.cpu() - ref).abs().max()), "attn_max": round(float(ref.max()), 4),
                                 "tiles_checked": pick, "weights": wset}
     linf = linf_by_set["init"]["linf"]
+    if fast is not None:  # the peaked set's reference was computed in the loop above
+        sdp = synth.synth_arch_state_dict(args.arch, p, seed=0, variant="peaked")
+        refp = O.get_last_selfattention(sdp, O.make_cfg(sdp, p, H), x[pick].cpu())
+        fast["attn_linf_peaked_weights"] = float((ob_pick - refp).abs().max())
 
     # HBM bytes per launch of the dominant class: measured offline with rocprofv3 --pmc (separate passes,
     # gfx950 FETCH_SIZE correction) and committed under profiles/; only valid for the default workload
@@ -390,36 +429,6 @@ def main():
             traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[args.precision][dom]["traffic_bytes"]
         except (OSError, KeyError, ValueError):
             traffic = None
-    # the single-bf16 fast mode next to the headline (rank 0, same batch, no collective): what the extra precision costs
-    fast = None
-    if args.precision == "bf16x3" and default_workload:
-        model.load_state_dict(synth.synth_arch_state_dict(args.arch, p, seed=0, variant="peaked"))
-        model.set_precision("bf16")
-        ob = model._run(x, flags=flags)
-        sdp = synth.synth_arch_state_dict(args.arch, p, seed=0, variant="peaked")
-        refp = O.get_last_selfattention(sdp, O.make_cfg(sdp, p, H), x[pick].cpu())
-        peaked_bf16 = float((ob["attn"][0][pick].cpu() - refp).abs().max())
-        for _ in range(3):
-            model._run(x, flags=flags)
-        torch.cuda.synchronize()
-        _lib.check(lib.ocm_prof_begin(1 << _lib.KERNEL_CLASSES.index("fc1_gemm"), args.steps * L + 8))
-        tb = time.perf_counter()
-        for _ in range(args.steps):
-            model._run(x, flags=flags)
-        torch.cuda.synchronize()
-        dtb = time.perf_counter() - tb
-        _lib.check(lib.ocm_prof_end(ms, cnt))
-        i1 = _lib.KERNEL_CLASSES.index("fc1_gemm")
-        fc1_s = ms[i1] / max(cnt[i1], 1) * 1e-3
-        fast = {"dtype": "bf16", "value": round(B * args.steps / dtb, 1), "unit": "tiles/s (this rank)",
-                "ms_per_step": round(dtb / args.steps * 1e3, 4), "attn_linf_peaked_weights": peaked_bf16,
-                "note": "single bf16 MFMA operands: ~1.75x the throughput, but 4-8e-2 off the reference on peaked (trained-like) "
-                        "attention, 40-80x the north star's 1e-3 -> not the headline",
-                "roofline": {"bound": "mfma", "kernel": "fc1_gemm", "achieved": round(cf["fc1_gemm"] / fc1_s / 1e12, 2),
-                             "peak": PEAK_BF16_DENSE_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(cf["fc1_gemm"] / fc1_s / 1e12 / PEAK_BF16_DENSE_TFLOPS, 4),
-                             "avg_launch_us": round(fc1_s * 1e6, 2)}}
-        model.set_precision(args.precision)
     tiles = B * world * args.steps
     value = tiles / dt
     dom_avg_s = dom_ms / max(dom_n, 1) * 1e-3
