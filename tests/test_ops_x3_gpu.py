@@ -164,6 +164,46 @@ def test_attention_x3(lib, dev, B, N, H, sharp):
     assert (rows.double() - pref.reshape(B, H, N, N)[:, :, rows_idx.long(), 1:]).abs().max().item() < 2e-5 * es
 
 
+@pytest.mark.parametrize("B,N,H,spike_at", [(2, 197, 3, 100), (1, 2305, 2, 1500), (2, 577, 2, 40), (1, 197, 1, 0)])
+def test_attention_x3_deferred_max_is_exact_when_the_maximum_jumps(lib, dev, B, N, H, spike_at):
+    """The flash kernels move a row's reference point only when some row of the wavefront found a score more than 8 (log2
+    units) above its own (kernels_attn.hip: defer_max_update; cdna_hip_programming.md T13 and its rule 26). The rare branch —
+    a rescale after many deferred tiles — needs an input that forces it: scores that stay within the threshold for every tile
+    (|q|, |k| ~ 0.5: the maximum creeps, nothing rescales) except ONE key whose row is a large multiple of a query direction, so
+    that at its tile the maximum of most rows jumps by tens of units and everything accumulated against the stale reference
+    (O, l) must be rescaled exactly once. Against float64 on the FULL tensor: context, log-sum-exp and probabilities."""
+    g = torch.Generator().manual_seed(61)
+    q = (torch.randn((B * H, N, 64), generator=g) * 0.5)
+    k = (torch.randn((B * H, N, 64), generator=g) * 0.5)
+    v = torch.randn((B * H, N, 64), generator=g)
+    k[:, spike_at] = 6.0 * q[:, N // 2] + 3.0 * q[:, 1]  # scores of ~100 against those queries, large against their neighbours
+    q, k, v = q.to(dev), k.to(dev), v.to(dev)
+    npad = lib.ocm_n_pad_prec(X3, N)
+    nan = float("nan")
+    qp = torch.full((B * H, npad, 64), nan, device=dev)
+    kp = torch.full((B * H, npad, 64), nan, device=dev)
+    vp = torch.full((B * H, 64, npad), nan, device=dev)
+    qp[:, :N], kp[:, :N], vp[:, :, :N] = q, k, v.transpose(1, 2)
+    qs, ks, vs = to_operand(qp, X3), to_operand(kp, X3), to_operand(vp, X3)
+    scale = 0.125
+    s = (q.double() @ k.double().transpose(1, 2)) * scale
+    assert float((s.max(-1).values - s.median(-1).values).max()) * math.log2(math.e) > 16  # the jump is far past the threshold
+    pref = s.softmax(-1)
+    oref = (pref @ v.double()).reshape(B, H, N, 64).permute(0, 2, 1, 3).reshape(B, N, H * 64)
+    ctx = torch.full((B, N, H * 64), nan, device=dev).view(torch.int32)
+    lse = torch.empty((B * H, N), device=dev)
+    _ok(lib, lib.ocm_op_attention(X3, _p(qs), _p(ks), _p(vs), _p(ctx), _p(lse), B, N, H, scale, _s()))
+    es = float(s.abs().max()) / 8  # operand rounding is relative: the score error scales with the largest score
+    assert (lse.double() - torch.logsumexp(s, -1) / math.log(2.0)).abs().max().item() < 2e-4 * max(1.0, es)
+    got = from_split(ctx).double()
+    assert torch.isfinite(got).all()
+    assert (got - oref).abs().max().item() < 1e-4 * max(1.0, es)
+    attn = torch.full((B, H, N, N), nan, device=dev)
+    _ok(lib, lib.ocm_op_attention_probs(X3, _p(qs), _p(ks), _p(lse), _p(attn), B, N, H, scale, _s()))
+    assert (attn.reshape(B * H, N, N).double() - pref).abs().max().item() < 1e-4 * max(1.0, es)
+    assert (attn.sum(-1) - 1).abs().max().item() < 1e-4
+
+
 @pytest.mark.parametrize("B,N,H", [(2, 65, 3), (1, 197, 3), (3, 300, 2), (1, 32, 1)])
 @pytest.mark.parametrize("sharp", [1.0, 2.0])
 def test_attention_x3_128_wide_heads(lib, dev, B, N, H, sharp):

@@ -5,7 +5,8 @@
 
 For every shape: bit-identity of context rows and log-sum-exp between knob 6 = 0 (the shipped dispatch: attn_fwd_x3_pp_kernel,
 software-pipelined blocks, for N <= 1024; attn_fwd_x3_dma_kernel on eight waves above that) and the other variants (3 = the
-round-3 loop attn_fwd_x3_dma_kernel on four waves, 1 = the register-staged kernel), NaN-poisoned padding; then alternating
+round-3 loop attn_fwd_x3_dma_kernel on four waves; 1 = the register-staged kernel, whose 64-key tiles take the deferred-maximum
+decisions at other points and therefore agrees to rounding only), NaN-poisoned padding; then alternating
 timings with hipEvents (median of rounds). In-forward numbers: tools/ab_bench.sh "6=0" "6=3".
 """
 import argparse

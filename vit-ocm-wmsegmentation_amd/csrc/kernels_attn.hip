@@ -33,6 +33,27 @@ int ocm_wt_mask();  // kernels_gemm.hip
 #include "dev_knobs.h"
 #define OCM_VMCNT_ATTN(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
+// Deferred running maximum of the split-bf16 flash kernels (cdna_hip_programming.md T13). The reference point m of a query row
+// only moves when some row of the wavefront found a score more than OCM_DEFER_MAX (log2 units) above its own m; until then the
+// tile's exponentials are taken against the old m — values up to 2^OCM_DEFER_MAX, exact in fp32 and as split pairs (this mode keeps
+// P at 2^-17 relative whatever its magnitude; a single-bf16 P would lose three bits) — and neither O nor l is rescaled. Any
+// reference point gives the same softmax (lse2 = m + log2 l; the key-split merge and the probability kernels only see lse2 / (m, l)),
+// so results change in the last bits only. With near-uniform attention the true maximum creeps up in most tiles of a long
+// sequence (at N = 2305 some row of a wavefront moved in more than half of the 73 tiles): 16 packed multiplies of O and the
+// branch around them per tile. Returns the factor for O and l (1 when nothing moved); m is updated in place.
+#ifndef OCM_DEFER_MAX
+#define OCM_DEFER_MAX 8.0f  // (0: the reference point follows every new maximum, the round-3 behaviour — A/B builds)
+#endif
+__device__ __forceinline__ float defer_max_update(float &m, float cand) {
+    if (__any(cand > m + OCM_DEFER_MAX)) {  // m = -inf in front of the first tile: true
+        const float mn = fmaxf(m, cand);
+        const float alpha = fast_exp2(m - mn);
+        m = mn;
+        return alpha;
+    }
+    return 1.0f;
+}
+
 template <bool WANT_O>
 // compiled for three waves per SIMD (<= 168 registers, no spills): the softmax VALU work of one wave overlaps the
 // MFMAs of the others (+17..24 % over the two-wave allocation hipcc picks by itself)
@@ -735,9 +756,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_fwd_x3_kernel(const char *__r
 #pragma unroll
             for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(S[0][e], S[1][e]));
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m, mx * scale2);  // finite: every tile holds at least one valid key
-            const float alpha = fast_exp2(m - mn);
-            m = mn;
+            const float alpha = defer_max_update(m, mx * scale2);  // every tile holds at least one valid key: finite
+            const float mn = m;
             float ps = 0.f;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
@@ -1015,9 +1035,8 @@ __global__ __launch_bounds__(NW * 64, WPS) void attn_fwd_x3_dma_kernel(const cha
 #pragma unroll
             for (int e = 1; e < 16; ++e) mx = fmaxf(mx, S[e]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m, mx * scale2);  // finite: every tile holds at least one valid key
-            const float alpha = fast_exp2(m - mn);
-            m = mn;
+            const float alpha = defer_max_update(m, mx * scale2);  // every tile holds at least one valid key: finite
+            const float mn = m;
             float ps = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -1269,9 +1288,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_x3_pp_kernel(const char *__re
 #pragma unroll
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, S[e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx * scale2);  // finite: every tile holds at least one valid key
-        const float alpha = fast_exp2(m - mn);
-        m = mn;
+        const float alpha = defer_max_update(m, mx * scale2);  // every tile holds at least one valid key: finite
+        const float mn = m;
         float ps = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -1530,9 +1548,8 @@ __global__ __launch_bounds__(512, 2) void attn_small_x3_kernel(const char *__res
 #pragma unroll
         for (int e = 1; e < 16; ++e) mx = fmaxf(mx, fmaxf(S[0][e], S[1][e]));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx * scale2);
-        const float alpha = fast_exp2(m - mn);
-        m = mn;
+        const float alpha = defer_max_update(m, mx * scale2);  // every tile holds at least one valid key: finite
+        const float mn = m;
         float ps = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
