@@ -1412,6 +1412,236 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_x3_pp_kernel(const char *__re
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Wave-split form for a handful of workgroups (one tile per call: ViT-S/16 at B = 1 is 12 workgroups of the kernel above, each
+// walking its seven key tiles one barrier at a time on one wave per SIMD — 11.5 us for 0.1 us of matrix work). Here a workgroup
+// is ONE 32-query tile of one (image, head) and its four waves split the KEYS: wave w takes key tiles w, w + 4, ... into a
+// private two-slot LDS ring (no workgroup barrier in the loop: a wave waits for its own LDS-DMA only), runs the usual
+// scores -> softmax -> P.V on them and leaves (m, l, O) in LDS; after the one barrier the four partial results are merged in a
+// fixed order (m = max m_w, L = sum l_w 2^(m_w - m), ctx = sum O_w 2^(m_w - m) / L: the flash-decoding reduction of
+// attn_merge_x3_kernel inside the workgroup), each wave finishing sixteen channels of the 32 queries as 16-byte pair stores.
+// 42 workgroups of at most two tiles per wave instead of 12 of seven. Chosen by launch_attention for N <= 1024 when the kernel
+// above would start fewer than 128 workgroups.
+template <bool WANT_O>
+__global__ __launch_bounds__(256) void attn_fwd_x3_ws_kernel(const char *__restrict__ Q, const char *__restrict__ Kk,
+                                                            const char *__restrict__ Vt, char *__restrict__ ctx,
+                                                            float *__restrict__ lse2, int N, int npad, int H, float scale2) {
+    constexpr int HD = 64, KB = HD * 128, SLOT = 2 * KB;  // a private slot: K tile | V^T tile
+    extern __shared__ __attribute__((aligned(1024))) char smem[];  // 4 waves x 2 slots x 16 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int qt = blockIdx.x, bh = blockIdx.y;
+    const int q0 = qt * 32;
+    const char *Qb = Q + (int64_t)bh * npad * (HD * 4);
+    const char *Kb = Kk + (int64_t)bh * npad * (HD * 4);
+    const char *Vb = Vt + (int64_t)bh * HD * npad * 4;
+    const int nt = (N + 31) >> 5;
+    char *mine = smem + wave * 2 * SLOT;
+
+    bf16x8 qh[4], ql[4];
+    {
+        const char *qp = Qb + (int64_t)min(q0 + r, N - 1) * (HD * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const char *p = qp + (s >> 1) * 128 + ((s & 1) * 16 + 8 * h) * 2;
+            qh[s] = *(const bf16x8 *)p;
+            ql[s] = *(const bf16x8 *)(p + 64);
+        }
+    }
+    // one wave fills a whole tile: pieces 0..7 of K (image pc >> 2, rows (pc & 3) * 8 ..) and of V^T (d rows pc * 8 ..)
+    int voffK[8], voffV[WANT_O ? 8 : 1];
+    {
+        const int lrow = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int pc = 0; pc < 8; ++pc) {
+            const int rho = (pc & 3) * 8 + lrow;
+            voffK[pc] = rho * (HD * 4) + (pc >> 2) * 128 + ((slot ^ ((rho >> 1) & 7)) << 4);
+            if (WANT_O) {
+                const int rv = pc * 8 + lrow;
+                voffV[pc] = rv * npad * 4 + ((slot ^ ((rv >> 1) & 7)) << 4);
+            }
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const auto rsK = __builtin_amdgcn_make_buffer_rsrc((void *)Kb, 0, (unsigned)(npad * HD * 4), 0x00020000);
+    const auto rsV = __builtin_amdgcn_make_buffer_rsrc((void *)Vb, 0, (unsigned)(HD * npad * 4), 0x00020000);
+#define OCM_WS_DMA(t, sl)                                                                                              \
+    do {                                                                                                               \
+        char *st_ = mine + (sl) * SLOT;                                                                                \
+        _Pragma("unroll") for (int pc = 0; pc < 8; ++pc)                                                               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(st_ + pc * 1024), 16, voffK[pc], (t) * (32 * HD * 4), 0, 0); \
+        if (WANT_O) {                                                                                                  \
+            _Pragma("unroll") for (int pc = 0; pc < 8; ++pc)                                                           \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(st_ + KB + pc * 1024), 16, voffV[pc], (t) * 128, 0, 0); \
+        }                                                                                                              \
+    } while (0)
+#else
+#define OCM_WS_DMA(t, sl) (void)0
+#endif
+    constexpr int LPT = WANT_O ? 16 : 8;  // LDS-DMA instructions per tile
+    const int mynt = wave < nt ? (nt - wave + 3) / 4 : 0;  // my tiles: wave, wave + 4, ...
+    if (mynt > 0) OCM_WS_DMA(wave, 0);
+    if (mynt > 1) OCM_WS_DMA(wave + 4, 1);
+
+    f32x16 O[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[0][e] = O[1][e] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const int pr = pi_row(r);
+    const int first_pad = N - (nt - 1) * 32;
+    for (int i = 0; i < mynt; ++i) {
+        const int t = wave + 4 * i, sl = i & 1;
+        // my own DMAs of tile i have landed once at most the next tile's are pending (the builtin for the first: it also
+        // covers the Q registers, and hipcc must know they are complete)
+        if (i == 0) {
+            // s_waitcnt immediate (gfx9): vmcnt = bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at "no wait"
+            if (mynt > 1)
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (LPT & 15) | ((LPT >> 4) << 14));  // vmcnt(LPT)
+            else
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+        } else if (i + 1 < mynt) {
+            OCM_VMCNT_ATTN(LPT);
+        } else {
+            OCM_VMCNT_ATTN(0);
+        }
+        char *Kt = mine + sl * SLOT, *Vtile = Kt + KB;
+        const bool last_of_seq = t + 1 == nt;
+        if (WANT_O && last_of_seq && first_pad < 32) {  // zero the V^T columns of the padding keys (my own slot: no barrier)
+            const int kc = lane & 3;
+            if (kc * 8 + 8 > first_pad) {
+#pragma unroll
+                for (int d = lane >> 2; d < HD; d += 16)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        bf16x8 *p = (bf16x8 *)(Vtile + lds_off(d, half * 4 + kc));
+                        bf16x8 tv = *p;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (kc * 8 + e >= first_pad) tv[e] = (bf16)0.f;
+                        *p = tv;
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        f32x16 S;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const char *kp = Kt + (s >> 1) * 4096;
+            const bf16x8 kh = *(const bf16x8 *)(kp + lds_off(pr, (s & 1) * 2 + h));
+            const bf16x8 kl = *(const bf16x8 *)(kp + lds_off(pr, 4 + (s & 1) * 2 + h));
+            S = mfma32x3(kh, kl, qh[s], ql[s], S);
+        }
+        if (last_of_seq && first_pad < 32) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (key_of_reg(e, h) >= first_pad) S[e] = -INFINITY;
+        }
+        float mx = S[0];
+#pragma unroll
+        for (int e = 1; e < 16; ++e) mx = fmaxf(mx, S[e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float alpha = defer_max_update(m, mx * scale2);
+        float ps = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = fast_exp2(fmaf(S[e], scale2, -m));
+            S[e] = p;
+            ps += p;
+        }
+        l = fmaf(l, alpha, ps);
+        if (WANT_O) {
+            if (__any(alpha != 1.0f)) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    O[0][e] *= alpha;
+                    O[1][e] *= alpha;
+                }
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = S[8 * s2 + e];
+                    const bf16 tb = (bf16)pv;
+                    ph[e] = tb;
+                    pl[e] = (bf16)(pv - (float)tb);
+                }
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const char *vp = Vtile + db * 32 * 128;
+                    const bf16x8 vh = *(const bf16x8 *)(vp + lds_off(r, 2 * s2 + h));
+                    const bf16x8 vl = *(const bf16x8 *)(vp + lds_off(r, 4 + 2 * s2 + h));
+                    O[db] = mfma32x3(vh, vl, ph, pl, O[db]);
+                }
+            }
+        }
+        if (i + 2 < mynt) {  // refill this slot: my reads of it are done
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            OCM_WS_DMA(t + 8, sl);
+        }
+    }
+#undef OCM_WS_DMA
+    // publish (m, l, O) — in my own region, over my slots (their last reads are done) — then merge
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float *Om = (float *)mine;           // [64 d][32 q]
+    float *ml = (float *)(mine + 8192);  // m[32] | l[32]
+    const float lt = l + __shfl_xor(l, 32, 64);
+    if (h == 0) {
+        ml[r] = m;
+        ml[32 + r] = lt;
+    }
+    if (WANT_O) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Om[(32 * db + acc_row32(e, h)) * 32 + r] = O[db][e];
+    }
+    __syncthreads();
+    const int qrow = q0 + r;
+    float mw[4], lw[4], mm = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float *mlw = (const float *)(smem + w * 2 * SLOT + 8192);
+        mw[w] = mlw[r];
+        lw[w] = mlw[32 + r];
+        mm = fmaxf(mm, mw[w]);
+    }
+    float L = 0.f, wgt[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        wgt[w] = fast_exp2(mw[w] - mm);  // a wave without tiles left m = -inf, l = 0: weight 0
+        L = fmaf(lw[w], wgt[w], L);
+    }
+    if (lse2 && wave == 0 && h == 0 && qrow < N) lse2[(int64_t)bh * N + qrow] = mm + __log2f(L);
+    if (WANT_O) {
+        const float inv = 1.0f / L;
+        const int d0 = 16 * wave + 8 * h;  // this lane finishes channels d0 .. d0 + 7 of query r
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float *Ow = (const float *)(smem + w * 2 * SLOT);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o0[j] = fmaf(Ow[(d0 + j) * 32 + r], wgt[w], o0[j]);
+                o1[j] = fmaf(Ow[(d0 + 4 + j) * 32 + r], wgt[w], o1[j]);
+            }
+        }
+        if (qrow < N) {
+            bf16x8 hi, lo;
+            split8(o0 * inv, o1 * inv, hi, lo);
+            const int b = bh / H, head = bh - b * H;
+            char *dst = ctx + ((int64_t)b * N + qrow) * (H * HD) * 4 + head * (HD * 4) + (d0 >> 5) * 128 + (d0 & 31) * 2;
+            *(bf16x8 *)dst = hi;
+            *(bf16x8 *)(dst + 64) = lo;
+        }
+    }
+}
+
 // Combines the key slices of attn_fwd_x3_dma_kernel<..., KSPLIT>: 16 lanes per query row (four channels each),
 //   m = max_s m_s,  L = sum_s l_s 2^(m_s - m),  ctx = sum_s O_s 2^(m_s - m) / L  (as split pairs),  lse2 = m + log2 L.
 template <int HD>
@@ -1897,6 +2127,26 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
 #endif
         if (wide) {
             if (ctx) OCM_X3_ATTN_DMA(true, 8, 2, grid8, block8); else OCM_X3_ATTN_DMA(false, 8, 2, grid8, block8);
+        } else if (grid.x * grid.y < 128 && OCM_KNOB(6) != 4 && OCM_KNOB(6) != 3) {
+            // a handful of workgroups (one tile per call): the keys of a 32-query tile split over the four waves of a workgroup
+            const dim3 gws(qtiles, batch * heads);
+            constexpr int LDSWS = 4 * 2 * 2 * 8192;
+            static unsigned long long optin[2] = {0, 0};
+            int dev = 0;
+            if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+            const void *kern = ctx ? (const void *)attn_fwd_x3_ws_kernel<true> : (const void *)attn_fwd_x3_ws_kernel<false>;
+            unsigned long long &mask = optin[ctx ? 1 : 0];
+            if (!(mask >> (dev & 63) & 1)) {
+                if (hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSWS); e != hipSuccess)
+                    return e;
+                mask |= 1ull << (dev & 63);
+            }
+            if (ctx)
+                attn_fwd_x3_ws_kernel<true><<<gws, block, LDSWS, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx,
+                                                                      lse2, n_tokens, n_pad, heads, scale * LOG2E);
+            else
+                attn_fwd_x3_ws_kernel<false><<<gws, block, LDSWS, s>>>((const char *)q, (const char *)k, (const char *)vt, (char *)ctx,
+                                                                       lse2, n_tokens, n_pad, heads, scale * LOG2E);
         } else if (OCM_KNOB(6) == 3) {  // development A/B: the round-3 loop on four waves (shipped: the software-pipelined kernel)
             if (ctx) OCM_X3_ATTN_DMA(true, 4, 3, grid, block); else OCM_X3_ATTN_DMA(false, 4, 3, grid, block);
         } else if (ctx) {
