@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCM_ABI_VERSION 7
+#define OCM_ABI_VERSION 8
 
 enum {
     OCM_OK = 0,
@@ -307,6 +307,9 @@ int ocm_op_tile_postprocess(const float *rows, float *maps, int32_t tiles, int32
  * border, fp32 (cv2 is an un-vendored dependency: parity unpinned). */
 int ocm_op_bilinear_upsample(const float *src, float *dst, int32_t tiles, int32_t h, int32_t w, int32_t scale,
                              void *stream);
+/* Nearest-neighbour x`rep` of (T,h,w) float32 maps (index replication: compute_attention's nearest upsample utils.py:233,
+ * the block values of the //8 *8 resize chain sw_processing.py:255-257, the patch mask of model.py:71): dst (T,h*rep,w*rep). */
+int ocm_op_nearest_upsample(const float *src, float *dst, int32_t tiles, int32_t h, int32_t w, int32_t rep, void *stream);
 /* concat_crops :113-149 — n x n row-major float32 windows (n*n, window, window) -> (S,S),
  * S = window + (n-1)*stride; ramp = np.linspace(1, 0, window - stride) as float64 on device.
  * Bit-exact with the reference's sequential stitcher. stride < window <= 3*stride. */

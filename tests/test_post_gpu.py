@@ -300,3 +300,20 @@ def test_segment_images_median_filter_and_crops(dev, median):
     # block-centre pixels the down-scale samples lies inside one constant block: the identity
     base = average_attention_maps(model, crops.to(dev), median_filter=1).cpu().numpy()
     assert (np.abs(maps - base).max() > 0) == (median == 13)
+
+
+@pytest.mark.parametrize("T,h,w,rep", [(3, 14, 14, 16), (2, 48, 48, 8), (1, 5, 7, 3), (4, 6, 6, 1)])
+def test_nearest_upsample_is_index_replication(dev, lib, T, h, w, rep):
+    """ocm_op_nearest_upsample: dst[t][y][x] = src[t][y // rep][x // rep] — bit for bit what np.repeat /
+    F.interpolate(mode="nearest") with an integer factor give (utils.py:233 compute_attention, the //8 *8 block values of
+    sw_processing.py:255-257, the patch mask of model.py:71)."""
+    import ctypes as C
+    from vit_ocm_wmsegmentation_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    src = torch.randn((T, h, w), generator=g).to(dev)
+    dst = torch.full((T, h * rep, w * rep), float("nan"), device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ocm_op_nearest_upsample(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), T, h, w, rep, st))
+    want = src.repeat_interleave(rep, 1).repeat_interleave(rep, 2)
+    assert torch.equal(dst, want)
+    assert lib.ocm_op_nearest_upsample(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), T, h, w, 0, st) == _lib.OCM_EINVAL

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OCM_VIT_LIB lets kernel experiments A/B two builds of the same ABI; the default is the in-tree build.
 LIB_PATH = os.environ.get("OCM_VIT_LIB") or os.path.join(_HERE, "libocm_vit.so")
 
-OCM_ABI_VERSION = 7
+OCM_ABI_VERSION = 8
 OCM_OK, OCM_EINVAL, OCM_ESTATE, OCM_EHIP, OCM_ENOMEM, OCM_ENAME = 0, 1, 2, 3, 4, 5
 
 OCM_PREC_BF16 = 0
@@ -136,6 +136,7 @@ SIGNATURES = {
     "ocm_op_attention_map": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_tile_postprocess": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_bilinear_upsample": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "ocm_op_nearest_upsample": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_stitch": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "ocm_op_normalize_u8": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "ocm_otsu_threshold": (_i32, [C.POINTER(C.c_uint64), _i64]),

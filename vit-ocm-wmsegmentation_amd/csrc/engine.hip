@@ -921,6 +921,14 @@ extern "C" int ocm_op_bilinear_upsample(const float *src, float *dst, int32_t ti
     return OCM_OK;
 }
 
+extern "C" int ocm_op_nearest_upsample(const float *src, float *dst, int32_t tiles, int32_t h, int32_t w, int32_t rep,
+                                       void *stream) {
+    if (!src || !dst) return fail(OCM_EINVAL, "null argument");
+    if (tiles <= 0 || h <= 0 || w <= 0 || rep <= 0) return fail(OCM_EINVAL, "bad shape");
+    HIP_TRY(launch_nearest_up(src, dst, tiles, h, w, rep, (hipStream_t)stream));
+    return OCM_OK;
+}
+
 extern "C" int ocm_op_stitch(const float *crops, float *out, const double *ramp, int32_t n, int32_t window,
                              int32_t stride, void *stream) {
     if (!crops || !out || !ramp) return fail(OCM_EINVAL, "null argument");

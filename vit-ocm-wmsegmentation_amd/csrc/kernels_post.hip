@@ -91,6 +91,27 @@ __global__ __launch_bounds__(256) void bilinear_up_kernel(const float *__restric
     }
 }
 
+// Nearest-neighbour x`rep` of (T,h,w) maps: dst[t][y][x] = src[t][y / rep][x / rep] — pure index replication (what
+// np.repeat / F.interpolate(mode="nearest") with an integer factor and the //8 *8 resize chain of sw_processing.py:255-257 do)
+__global__ __launch_bounds__(256) void nearest_up_kernel(const float *__restrict__ src, float *__restrict__ dst, int h, int w,
+                                                         int rep) {
+    const int W = w * rep, Hh = h * rep;
+    const float *sp = src + (size_t)blockIdx.y * h * w;
+    float *dp = dst + (size_t)blockIdx.y * Hh * W;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Hh * W; i += gridDim.x * 256) {
+        const int y = i / W, x = i - y * W;
+        dp[i] = sp[(y / rep) * w + x / rep];
+    }
+}
+
+hipError_t launch_nearest_up(const float *src, float *dst, int tiles, int h, int w, int rep, hipStream_t s) {
+    if (tiles <= 0) return hipSuccess;
+    int bx = (h * rep * w * rep + 255) / 256;
+    if (bx > 64) bx = 64;
+    nearest_up_kernel<<<dim3(bx, tiles), dim3(256), 0, s>>>(src, dst, h, w, rep);
+    return hipGetLastError();
+}
+
 hipError_t launch_bilinear_up(const float *src, float *dst, int tiles, int h, int w, int scale, hipStream_t s) {
     if (tiles <= 0) return hipSuccess;
     int bx = (h * scale * w * scale + 255) / 256;

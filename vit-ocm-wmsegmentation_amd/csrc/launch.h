@@ -116,6 +116,7 @@ hipError_t launch_attention_map(const float *attn, float *maps, int b, int heads
 hipError_t launch_tile_postprocess(const float *rows, float *maps, int tiles, int heads, int n_rows, int pixels,
                                    hipStream_t s);
 hipError_t launch_bilinear_up(const float *src, float *dst, int tiles, int h, int w, int scale, hipStream_t s);
+hipError_t launch_nearest_up(const float *src, float *dst, int tiles, int h, int w, int rep, hipStream_t s);
 hipError_t launch_stitch(const float *crops, float *out, const double *ramp, int n, int window, int stride,
                          hipStream_t s);
 hipError_t launch_normalize_u8(const float *img, size_t count, float *part, uint8_t *out,

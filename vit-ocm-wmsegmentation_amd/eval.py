@@ -27,7 +27,8 @@ def _head_mean_small(model, tiles, median_filter):
         _lib.check(lib.ocm_op_head_mean(_p(rows), _p(small), T, Hh, nr, P, _stream()))
         k = int(median_filter)
         if k != 1:
-            up = small.repeat_interleave(p, 1).repeat_interleave(p, 2).contiguous()  # nearest x p: index replication
+            up = torch.empty((T, hf * p, wf * p), dtype=torch.float32, device=rows.device)  # nearest x p: index replication
+            _lib.check(lib.ocm_op_nearest_upsample(_p(small), _p(up), T, hf, wf, p, _stream()))
             filt = torch.empty_like(up)
             _lib.check(lib.ocm_op_median_filter(_p(up), _p(filt), T, hf * p, wf * p, k, _stream()))
             _lib.check(lib.ocm_op_downscale_centre(_p(filt), _p(small), T, hf * p, wf * p, p, _stream()))

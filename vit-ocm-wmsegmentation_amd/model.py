@@ -137,7 +137,12 @@ class MIM(nn.Module):
         x_rec = _conv1x1_pixel_shuffle(self.encoder, tokens, self.decoder[0], self.encoder_stride, self._dec_cache)
         # masked L1 reconstruction loss (model.py:71-73) — training bookkeeping, a handful of elementwise torch ops
         p = self.patch_size
-        pixel_mask = mask.repeat_interleave(p, 1).repeat_interleave(p, 2).unsqueeze(1).contiguous()
+        m32 = mask.to(torch.float32).contiguous()
+        pixel_mask = torch.empty((m32.shape[0], m32.shape[1] * p, m32.shape[2] * p), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.load().ocm_op_nearest_upsample(_p(m32), _p(pixel_mask), m32.shape[0], m32.shape[1], m32.shape[2], p,
+                                                           _stream()))
+        pixel_mask = pixel_mask.to(mask.dtype).unsqueeze(1)  # 0 / 1 values: exact in the caller's dtype
         err = (x - x_rec).abs() * pixel_mask
         loss = err.sum() / (pixel_mask.sum() + 1e-5) / self.in_chans
         return loss, x_rec, pixel_mask

@@ -83,7 +83,9 @@ def postprocess_windows(rows, hf, wf, patch_size):
     with _dev_call(rows):
         _lib.check(lib.ocm_op_tile_postprocess(C.c_void_p(rows.data_ptr()), C.c_void_p(small.data_ptr()), T, H, nr, P, st))
         if rep > 1:  # pure index replication (the block values the //8 resize lands on)
-            small = small.repeat_interleave(rep, 1).repeat_interleave(rep, 2).contiguous()
+            blocks = torch.empty((T, hf * rep, wf * rep), dtype=torch.float32, device=rows.device)
+            _lib.check(lib.ocm_op_nearest_upsample(C.c_void_p(small.data_ptr()), C.c_void_p(blocks.data_ptr()), T, hf, wf, rep, st))
+            small = blocks
         _lib.check(lib.ocm_op_bilinear_upsample(C.c_void_p(small.data_ptr()), C.c_void_p(big.data_ptr()), T, hf * rep,
                                                 wf * rep, scale, st))
     return big
