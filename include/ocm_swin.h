@@ -60,8 +60,9 @@ int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_t batch, fl
                      float *last_hidden, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Per-handle dispatch options. OCM_SWIN_OPT_FUSE_MLP (default 1): in split-bf16 precision the layers of the narrow stages
- * (96 or 128 channels) run their MLP half as ONE kernel (ocm_op_swin_mlp), and those of up to 192 channels layernorm_before +
- * the q | k | v projection as one (ocm_op_swin_lnqkv); 0 runs LayerNorm kernels and GEMMs. Results agree to fp32 rounding. */
+ * (96 or 128 channels) run their MLP half as ONE kernel (ocm_op_swin_mlp), those of up to 192 channels layernorm_before +
+ * the q | k | v projection as one (ocm_op_swin_lnqkv), and those of 96 channels their whole attention half as one
+ * (ocm_op_swin_attn_block); 0 runs LayerNorm kernels, GEMMs and the window-attention kernel. Results agree to fp32 rounding. */
 enum { OCM_SWIN_OPT_FUSE_MLP = 0 };
 int ocm_swin_set_option(ocm_swin_t *h, int32_t option, int32_t value);
 
@@ -78,6 +79,16 @@ int ocm_op_swin_lnqkv(int32_t precision, const float *x, const float *gamma, con
 int ocm_op_swin_mlp(int32_t precision, float *x, const float *gamma, const float *beta, const void *w1, const float *b1,
                     const void *w2, const float *b2, int64_t tokens, int32_t channels, int32_t hidden, float eps,
                     void *stream);
+
+/* Attention half of one SwinLayer (modeling_swin.py:641-666: layernorm_before, SwinSelfAttention with the relative-position
+ * bias and the shift mask, SwinSelfOutput, residual) in one kernel: x (batch * height * width, 32 * heads) fp32, in place,
+ * x += Wo window_attention(q | k | v of LayerNorm(x; gamma, beta, eps)) + bo. wqkv (3 * C, C) (rows q | k | v) and wo (C, C)
+ * as split pairs (ocm_op_cast_split); rel_table: (2*ws-1)^2 x heads fp32 device table; scratch: heads * 4096 floats of device
+ * memory. Built for OCM_PREC_BF16X3 and 3 heads (C = 96, stage 0 of Swin-T); anything else returns OCM_EINVAL. */
+int ocm_op_swin_attn_block(int32_t precision, float *x, const float *gamma, const float *beta, const void *wqkv,
+                           const float *bqkv, const void *wo, const float *bo, const float *rel_table, float *scratch,
+                           int32_t batch, int32_t height, int32_t width, int32_t window, int32_t shift, int32_t heads, float eps,
+                           void *stream);
 
 /* Stand-alone (shifted-)window attention of one SwinLayer (modeling_swin.py:529-563 without the projections):
  * qkv (B*H*W, ld) holds q | k | v (heads*32 channels each) per token in E = bf16 / fp32 / split-bf16 pairs (`precision`; pairs: ld and ldc multiples of 32);

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define OCM_ABI_VERSION 8
+#define OCM_ABI_VERSION 9
 
 enum {
     OCM_OK = 0,

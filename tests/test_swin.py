@@ -205,6 +205,65 @@ def test_swin_fused_lnqkv_op(lib, dev, T, Cn):
                                  st) == _lib.OCM_EINVAL
 
 
+def _attention_half_oracle(x, gam, bet, wqkv, bqkv, wo, bo, table, B, H, W, heads, ws, shift):
+    """x + o_proj(window attention of LayerNorm(x)) in float64: the first half of the oracle's swin_layer
+    (modeling_swin.py:641-666) on explicit tensors, wqkv rows q | k | v."""
+    F = torch.nn.functional
+    Cn, A = heads * 32, ws * ws
+    xd = x.double().view(B, H * W, Cn)
+    y = F.layer_norm(xd, (Cn,), gam.double(), bet.double(), 1e-5).view(B, H, W, Cn)
+    if shift:
+        y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
+    win = SO.window_partition(y, ws).view(-1, A, Cn)
+    q, k, v = [t.reshape(-1, A, heads, 32).transpose(1, 2) for t in (win @ wqkv.double().t() + bqkv.double()).split(Cn, -1)]
+    bias = table.double()[SO.relative_position_index(ws).view(-1)].view(A, A, -1).permute(2, 0, 1).unsqueeze(0)
+    mask = SO.shift_mask(H, W, ws, shift)
+    if mask is not None:
+        nW = mask.shape[0]
+        bias = bias + mask.double().unsqueeze(1).unsqueeze(0).expand(win.shape[0] // nW, -1, -1, -1, -1).reshape(-1, 1, A, A)
+    p = torch.softmax(q @ k.transpose(2, 3) * 32 ** -0.5 + bias, -1)
+    o = (p @ v).transpose(1, 2).reshape(-1, A, Cn) @ wo.double().t() + bo.double()
+    o = SO.window_reverse(o.view(-1, ws, ws, Cn), ws, H, W)
+    if shift:
+        o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    return xd + o.reshape(B, H * W, Cn)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,ws,shift", [(2, 14, 14, 7, 0), (2, 14, 14, 7, 3), (3, 7, 7, 7, 0), (1, 12, 8, 4, 2),
+                                            (2, 56, 56, 7, 3)])
+def test_swin_fused_attention_half_op(lib, dev, B, H, W, ws, shift):
+    """ocm_op_swin_attn_block (layernorm_before + q | k | v + (shifted-)window attention + o_proj + residual in one kernel,
+    split-bf16, 3 heads) against float64 torch (modeling_swin.py:641-666): plain and shifted windows, an odd number of
+    windows (one idle wavefront pair), a window side other than 7, and the stage-0 grid of Swin-T."""
+    from vit_ocm_wmsegmentation_amd.engine import to_operand
+    heads, Cn = 3, 96
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + shift)
+    x = torch.randn(B * H * W, Cn, generator=g) * 1.5 + 0.2
+    gam, bet = torch.randn(Cn, generator=g) * 0.2 + 1, torch.randn(Cn, generator=g) * 0.1
+    wqkv, bqkv = torch.randn(3 * Cn, Cn, generator=g) * 0.12, torch.randn(3 * Cn, generator=g) * 0.1
+    wo, bo = torch.randn(Cn, Cn, generator=g) * 0.1, torch.randn(Cn, generator=g) * 0.1
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g)
+    want = _attention_half_oracle(x, gam, bet, wqkv, bqkv, wo, bo, table, B, H, W, heads, ws, shift).view(-1, Cn)
+    xg = x.to(dev)
+    wq_s, wo_s = to_operand(wqkv.to(dev), _lib.OCM_PREC_BF16X3), to_operand(wo.to(dev), _lib.OCM_PREC_BF16X3)
+    dv = [t.to(dev) for t in (gam, bet, bqkv, bo, table)]
+    scratch = torch.empty(heads * 4096, dtype=torch.float32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ocm_op_swin_attn_block(_lib.OCM_PREC_BF16X3, p(xg), p(dv[0]), p(dv[1]), p(wq_s), p(dv[2]), p(wo_s), p(dv[3]),
+                                          p(dv[4]), p(scratch), B, H, W, ws, shift, heads, 1e-5, st))
+    got = xg.cpu().double()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    print(f"GPUTEST swin fused attention half B={B} {H}x{W} ws{ws} shift{shift}: max|d| = {err:.2e}")
+    assert err <= 1e-4
+    assert lib.ocm_op_swin_attn_block(_lib.OCM_PREC_BF16, p(xg), p(dv[0]), p(dv[1]), p(wq_s), p(dv[2]), p(wo_s), p(dv[3]), p(dv[4]),
+                                      p(scratch), B, H, W, ws, shift, heads, 1e-5, st) == _lib.OCM_EINVAL
+    assert lib.ocm_op_swin_attn_block(_lib.OCM_PREC_BF16X3, p(xg), p(dv[0]), p(dv[1]), p(wq_s), p(dv[2]), p(wo_s), p(dv[3]),
+                                      p(dv[4]), p(scratch), B, H, W, ws, shift, 6, 1e-5, st) == _lib.OCM_EINVAL
+
+
 @pytest.mark.gpu
 def test_swin_fused_mlp_agrees_with_three_launches(lib, dev):
     """OCM_SWIN_OPT_FUSE_MLP on / off (fused MLP and fused LayerNorm + qkv kernels of the narrow stage against LayerNorm kernels

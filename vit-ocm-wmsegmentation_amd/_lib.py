@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # OCM_VIT_LIB lets kernel experiments A/B two builds of the same ABI; the default is the in-tree build.
 LIB_PATH = os.environ.get("OCM_VIT_LIB") or os.path.join(_HERE, "libocm_vit.so")
 
-OCM_ABI_VERSION = 8
+OCM_ABI_VERSION = 9
 OCM_OK, OCM_EINVAL, OCM_ESTATE, OCM_EHIP, OCM_ENOMEM, OCM_ENAME = 0, 1, 2, 3, 4, 5
 
 OCM_PREC_BF16 = 0
@@ -154,6 +154,9 @@ SIGNATURES = {
                                     C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "ocm_op_swin_mlp": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "ocm_op_swin_attn_block": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "ocm_op_swin_window_attention": (C.c_int, [C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                                C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                C.c_int32, C.c_void_p]),

@@ -417,6 +417,7 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             case 12: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128q, E, 2>(a, K, w, K, M, N, K, epi, s); break;  // 8 waves
             case 13: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128q16, E, 2>(a, K, w, K, M, N, K, epi, s); break;
             case 14: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128m16, E, 2>(a, K, w, K, M, N, K, epi, s); break;
+            case 19: if (N % 256 == 0 && N >= 1024 && M >= 16384) return launch_gemm_dma<Cfg256x256m16, E, 2>(a, K, w, K, M, N, K, epi, s); break;
             default: break;
         }
 #endif
@@ -1020,6 +1021,7 @@ hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E
                 case 3: return launch_qkv_dma<Cfg64x128, E, 2>(a, w, M, D, eqk, ev, s);
                 case 4: if (D % 256 == 0) return launch_qkv_dma<Cfg256x256, E, 2>(a, w, M, D, eqk, ev, s); break;
                 case 5: return launch_qkv_dma<Cfg128x128q16, E, 2>(a, w, M, D, eqk, ev, s);
+                case 6: if (D % 256 == 0) return launch_qkv_dma<Cfg256x256m16, E, 2>(a, w, M, D, eqk, ev, s); break;
                 default: break;
             }
 #endif

@@ -1122,6 +1122,362 @@ hipError_t launch_swin_mlp(int prec, float *x, const float *g, const float *be, 
 }
 
 // ------------------------------------------------------------------------------------------
+// Attention half of a SwinLayer in one kernel (split-bf16, C = 96: stage 0 of Swin-T)
+//     x += o_proj(window_attention(q | k | v of LayerNorm(x)))      modeling_swin.py SwinLayer.forward :641-666
+// (layernorm_before :641, SwinSelfAttention :430-470 with the relative-position bias :329-370 and the shift mask :584-607,
+// SwinSelfOutput :476-484, the residual :664-666). Unfused, this half streams x, the q | k | v pairs (three times the size
+// of x), the context pairs and x again through HBM — 12 x the bytes of x per layer at 8e5 token rows; here a token's row is
+// read twice and written once, everything else stays on chip:
+//   * a workgroup = four wavefronts = TWO windows; wavefront (win, qt) owns window positions 32 qt .. 32 qt + 31 (49 real
+//     ones at ws = 7): LayerNorm of its rows in registers as the B operand x^T (swin_lnqkv_x3_kernel's scheme);
+//   * per head four steps on one weight chunk each (32 rows of Wq, Wk, Wv — pi order — or the head's 128-byte column group
+//     of all C rows of Wo; 4 KiB x C / 32 each) through a three-stage `buffer_load ... lds` ring shared by the four
+//     wavefronts, one counted vmcnt wait and one barrier per step:
+//       q: accumulator registers + bias, split -> ARE the B fragments of the score product (never leave registers);
+//       k, v: + bias, split -> the window's K image (64 keys x 128 B) and row-major V images (hi, lo) in LDS, padding keys 0;
+//       o: scores / softmax / context exactly as swin_wattn_x3_kernel (same operands, same order: the context pairs have
+//          the same bits as the unfused path's), V^T read from LDS with its rows in pi order, so that the normalised context
+//          registers ARE the B fragments of y^T (C x 32 tokens) += Wo[:, head] . ctx^T;
+//   * epilogue: + bias + x, fp32, in place (a window's tokens belong to no other window: no other wavefront reads them).
+// ------------------------------------------------------------------------------------------
+template <int CG, int WS>
+__global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__restrict__ x, const float *__restrict__ gam,
+                                                                    const float *__restrict__ bet, const char *__restrict__ wqkv,
+                                                                    const float *__restrict__ bqkv, const char *__restrict__ wo,
+                                                                    const float *__restrict__ bo,
+                                                                    const float *__restrict__ bias_perm, WinGeom g, int total,
+                                                                    float scale2, float eps) {
+    constexpr int C = CG * 32, HEADS = CG, NW = 4, CH = CG * 4096, NSTAGE = 3, PIECES = 4 * CG, PPW = PIECES / NW;
+    constexpr int NS = 2 * CG, NCH = 4 * HEADS, KV = 64 * 128 + 2 * 32 * 128 + 64;
+    static_assert(PIECES % NW == 0, "the wavefronts share the pieces of a chunk evenly");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int win = wave >> 1, qt = wave & 1;
+    char *Ks = smem + NSTAGE * CH + win * KV;  // K: 64 keys x 128 B (chunks 0..3 hi, 4..7 lo, lds_off swizzle)
+    char *Vh = Ks + 64 * 128, *Vl = Vh + 32 * 128;  // V hi / lo: [64 keys][32 dims] row-major, 64-byte rows
+    unsigned char *Rg = (unsigned char *)(Vl + 32 * 128);
+    float *bs = (float *)(smem + NSTAGE * CH + 2 * KV);  // bq | bk | bv | bo
+
+    int wid = blockIdx.x * 2 + win;
+    const bool wlive = wid < total;  // an odd window count leaves the last workgroup one idle pair (it keeps the barriers)
+    wid = min(wid, total - 1);
+    const int wlin = wid % g.nW, b = wid / g.nW;
+    const int wy = wlin / g.nWx, wx = wlin - wy * g.nWx;
+    const int ws = WS ? WS : g.ws;
+    const int A = ws * ws;
+    const int p = qt * 32 + r;  // window position = key index of this lane's token
+    const bool valid = p < A;
+    const size_t tok = win_token(g, ws, b, wy, wx, min(p, A - 1));
+
+    for (int i = tid; i < 3 * C; i += NW * 64) bs[i] = bqkv[i];
+    for (int i = tid; i < C; i += NW * 64) bs[3 * C + i] = bo[i];
+    const bool masked = g.shift > 0 && (wy == g.H / ws - 1 || wx == g.nWx - 1);  // wave-uniform
+    if (masked && qt == 0) Rg[lane] = (unsigned char)(lane < A ? win_region(g, ws, wy, wx, lane) : 0);
+
+    int voffA[PPW], voffB[PPW];
+    {
+        const int lrow = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int jj = 0; jj < PPW; ++jj) {
+            const int pc = jj * NW + wave;
+            const int rho = (pc & 3) * 8 + lrow;  // q / k / v chunk: image pc >> 2 = k group, rows (pc & 3) * 8 .. + 7
+            voffA[jj] = rho * (C * 4) + (pc >> 2) * 128 + ((slot ^ ((rho >> 1) & 7)) << 4);
+            const int c = pc * 8 + lrow;  // o_proj chunk: rows pc * 8 .. + 7 of the C outputs, the head's k group
+            voffB[jj] = c * (C * 4) + ((slot ^ ((c >> 1) & 7)) << 4);
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+    const auto rsq = __builtin_amdgcn_make_buffer_rsrc((void *)wqkv, 0, (unsigned)(3 * C * C * 4), 0x00020000);
+    const auto rso = __builtin_amdgcn_make_buffer_rsrc((void *)wo, 0, (unsigned)(C * C * 4), 0x00020000);
+    // chunk j = 4 * head + kind (kind 0 .. 2: rows kind * C + 32 head .. + 31 of Wqkv; kind 3: column group `head` of Wo)
+#define OCM_AB_DMA(j, st)                                                                                               \
+    do {                                                                                                                \
+        const int kind_ = (j) & 3, head_ = (j) >> 2;                                                                    \
+        if (kind_ < 3) {                                                                                                \
+            _Pragma("unroll") for (int jj = 0; jj < PPW; ++jj)                                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(smem + (st) * CH + (jj * NW + wave) * 1024), 16, \
+                                                         voffA[jj], (kind_ * C + head_ * 32) * (C * 4), 0, 0);          \
+        } else {                                                                                                        \
+            _Pragma("unroll") for (int jj = 0; jj < PPW; ++jj)                                                          \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rso, (lds_ptr)(smem + (st) * CH + (jj * NW + wave) * 1024), 16, \
+                                                         voffB[jj], head_ * 128, 0, 0);                                 \
+        }                                                                                                               \
+    } while (0)
+#else
+#define OCM_AB_DMA(j, st) (void)0
+#endif
+    OCM_AB_DMA(0, 0);
+    OCM_AB_DMA(1, 1);
+
+    // LayerNorm of the wave's rows: lane (r, h) holds channels 16 s + 8 h .. + 7 of its token for every slice s
+    bf16x8 xh[NS], xl[NS];
+    {
+        const float *xr = x + tok * C + 8 * h;
+        f32x4 v[NS][2];
+        float sum = 0.f;
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            v[sI][0] = *(const f32x4 *)(xr + 16 * sI);
+            v[sI][1] = *(const f32x4 *)(xr + 16 * sI + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum += v[sI][0][e] + v[sI][1][e];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / C);
+        float var = 0.f;
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d0 = v[sI][0][e] - mean, d1 = v[sI][1][e] - mean;
+                var = fmaf(d0, d0, fmaf(d1, d1, var));
+            }
+        var += __shfl_xor(var, 32, 64);
+        const float rstd = rsqrtf(var * (1.0f / C) + eps);
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            const f32x4 g0 = *(const f32x4 *)(gam + 16 * sI + 8 * h), g1 = *(const f32x4 *)(gam + 16 * sI + 8 * h + 4);
+            const f32x4 e0 = *(const f32x4 *)(bet + 16 * sI + 8 * h), e1 = *(const f32x4 *)(bet + 16 * sI + 8 * h + 4);
+            split8((v[sI][0] - mean) * rstd * g0 + e0, (v[sI][1] - mean) * rstd * g1 + e1, xh[sI], xl[sI]);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // rows, parameters and the first two chunks have landed (see swin_mlp_x3_kernel)
+
+    f32x16 Y[CG];
+#pragma unroll
+    for (int mf = 0; mf < CG; ++mf)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Y[mf][e] = 0.f;
+    const int pr = pi_row(r);
+    int sc = 0, si = NSTAGE - 1;
+    // top of step j: own pieces of chunk j have landed (chunk j + 1 may still be on its way), everybody's have after the
+    // barrier, and everybody is past the stage that chunk j + 2 goes into
+#define OCM_AB_TOP(j)                                                                  \
+    do {                                                                               \
+        if ((j) + 1 < NCH)                                                             \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");                 \
+        else                                                                           \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             \
+        __builtin_amdgcn_s_barrier();                                                  \
+        asm volatile("" ::: "memory");                                                 \
+    } while (0)
+#define OCM_AB_NEXT()                              \
+    do {                                           \
+        sc = sc == NSTAGE - 1 ? 0 : sc + 1;        \
+        si = si == NSTAGE - 1 ? 0 : si + 1;        \
+    } while (0)
+    // 32 output features of the chunk in stage sc for the wave's 32 tokens: register e of lane half h = feature key_of_reg(e, h)
+    auto project = [&](f32x16 &S) {
+        const char *Wst = smem + sc * CH;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) S[e] = 0.f;
+#pragma unroll
+        for (int sI = 0; sI < NS; ++sI) {
+            const char *img = Wst + (sI >> 1) * 4096;
+            const bf16x8 ah = *(const bf16x8 *)(img + lds_off(pr, (sI & 1) * 2 + h));
+            const bf16x8 al = *(const bf16x8 *)(img + lds_off(pr, 4 + (sI & 1) * 2 + h));
+            S = mfma32x3(ah, al, xh[sI], xl[sI], S);
+        }
+    };
+    // registers 8 s2 .. 8 s2 + 7 (features 16 s2 + 8 h .. + 7) + bias, as a pair of fragments
+    auto biased_pair = [&](const f32x16 &S, const float *bvec, int s2, bf16x8 &ph, bf16x8 &pl) {
+        const float *bp = bvec + 16 * s2 + 8 * h;
+        const f32x4 c0 = *(const f32x4 *)bp, c1 = *(const f32x4 *)(bp + 4);
+        f32x4 u0, u1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u0[e] = S[8 * s2 + e] + c0[e];
+            u1[e] = S[8 * s2 + 4 + e] + c1[e];
+        }
+        split8(u0, u1, ph, pl);
+    };
+    const bf16x8 zero8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+
+    for (int head = 0; head < HEADS; ++head) {
+        const int j0 = 4 * head;
+        f32x16 S;
+        bf16x8 qh[2], ql[2];
+        // ---- q
+        OCM_AB_TOP(j0);
+        OCM_AB_DMA(j0 + 2, si);
+        project(S);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) biased_pair(S, bs + head * 32, s2, qh[s2], ql[s2]);
+        OCM_AB_NEXT();
+        // ---- k -> the window's K image, row p
+        OCM_AB_TOP(j0 + 1);
+        OCM_AB_DMA(j0 + 3, si);
+        project(S);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 ph, pl;
+            biased_pair(S, bs + C + head * 32, s2, ph, pl);
+            *(bf16x8 *)(Ks + lds_off(p, 2 * s2 + h)) = valid ? ph : zero8;
+            *(bf16x8 *)(Ks + lds_off(p, 4 + 2 * s2 + h)) = valid ? pl : zero8;
+        }
+        OCM_AB_NEXT();
+        // ---- v -> the window's V images, row p
+        OCM_AB_TOP(j0 + 2);
+        if (j0 + 4 < NCH) OCM_AB_DMA(j0 + 4, si);
+        project(S);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 ph, pl;
+            biased_pair(S, bs + 2 * C + head * 32, s2, ph, pl);
+            *(bf16x8 *)(Vh + p * 64 + (2 * s2 + h) * 16) = valid ? ph : zero8;
+            *(bf16x8 *)(Vl + p * 64 + (2 * s2 + h) * 16) = valid ? pl : zero8;
+        }
+        OCM_AB_NEXT();
+        // ---- scores, softmax, context (swin_wattn_x3_kernel for this wave's query tile), then y^T += Wo[:, head] . ctx^T
+        OCM_AB_TOP(j0 + 3);
+        f32x16 S2[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) S2[sub][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 kh = *(const bf16x8 *)(Ks + lds_off(sub * 32 + pr, 2 * s + h));
+                const bf16x8 kl = *(const bf16x8 *)(Ks + lds_off(sub * 32 + pr, 4 + 2 * s + h));
+                S2[sub] = mfma32x3(kh, kl, qh[s], ql[s], S2[sub]);
+            }
+        }
+        const float *bq = bias_perm + ((size_t)head * 2 + qt) * 64 * 32 + lane * 4;
+        float mx = -INFINITY;
+        const int myreg = masked ? Rg[min(p, A - 1)] : 0;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                const f32x4 bv = *(const f32x4 *)(bq + (sub * 4 + e4) * 256);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = fmaf(S2[sub][e4 * 4 + e], scale2, bv[e]);
+                    if (masked) {
+                        const int jk = sub * 32 + key_of_reg(e4 * 4 + e, h);
+                        if (jk < A && Rg[jk] != myreg) v += -100.0f * 1.4426950408889634f;
+                    }
+                    S2[sub][e4 * 4 + e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float l = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = fast_exp2(S2[sub][e] - mx);
+                S2[sub][e] = pv;
+                l += pv;
+            }
+        l += __shfl_xor(l, 32, 64);
+        // the bias loads above are consumed: the next chunk's DMA is issued only now (hipcc drains every vector-memory
+        // operation in front of the first use of an ordinary load's result while an LDS-DMA is in flight)
+        if (j0 + 5 < NCH) OCM_AB_DMA(j0 + 5, si);
+        f32x16 O;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[e] = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = S2[sub][8 * s2 + e];
+                    const bf16 t = (bf16)pv;
+                    ph[e] = t;
+                    pl[e] = (bf16)(pv - (float)t);
+                }
+                // V^T rows in pi order: lane 4 q + pp of a 16-lane group addresses key row q, dims 4 swap(pp) .. + 3, so that
+                // column slot i of the group receives dim pi_row(i) and accumulator register e of lane half h holds dim
+                // key_of_reg(e, h): registers 8 s .. 8 s + 7 are the B fragment (k = 16 s + 8 h ..) of the o_proj product
+                const int pp = lane & 3, pps = ((pp & 1) << 1) | (pp >> 1);
+                const int voff = (sub * 32 + 16 * s2 + 8 * h + ((lane >> 2) & 3)) * 64 + (16 * ((lane >> 4) & 1) + 4 * pps) * 2;
+                const bf16x8 vh = tr_read8(Vh + voff), vl = tr_read8(Vl + voff);
+                O = mfma32x3(vh, vl, ph, pl, O);
+            }
+        {
+            const float inv = 1.0f / l;
+            const char *Wos = smem + sc * CH;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f32x4 o0, o1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o0[e] = O[8 * s2 + e] * inv;
+                    o1[e] = O[8 * s2 + 4 + e] * inv;
+                }
+                bf16x8 ch, cl;
+                split8(o0, o1, ch, cl);
+#pragma unroll
+                for (int mf = 0; mf < CG; ++mf) {
+                    const bf16x8 wh = *(const bf16x8 *)(Wos + lds_off(32 * mf + r, 2 * s2 + h));
+                    const bf16x8 wl = *(const bf16x8 *)(Wos + lds_off(32 * mf + r, 4 + 2 * s2 + h));
+                    Y[mf] = mfma32x3(wh, wl, ch, cl, Y[mf]);
+                }
+            }
+        }
+        OCM_AB_NEXT();
+    }
+#undef OCM_AB_DMA
+#undef OCM_AB_TOP
+#undef OCM_AB_NEXT
+    if (!valid || !wlive) return;
+    // y^T: lane (r, h) register 4 gq + e of fragment mf = channel 32 mf + 8 gq + 4 h + e of the lane's token
+    float *xo = x + tok * C;
+#pragma unroll
+    for (int mf = 0; mf < CG; ++mf)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int c = 32 * mf + 8 * gq + 4 * h;
+            const f32x4 old = *(const f32x4 *)(xo + c), bb = *(const f32x4 *)(bs + 3 * C + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = Y[mf][4 * gq + e] + bb[e] + old[e];
+            *(f32x4 *)(xo + c) = o;
+        }
+}
+
+bool swin_attn_block_fused_supported(int prec, int C, int heads, int ws) {
+    return prec == 2 && C == 96 && heads * 32 == C && ws >= 2 && ws * ws <= 64;
+}
+
+hipError_t launch_swin_attn_block(int prec, float *x, const float *g, const float *be, const void *wqkv, const float *bqkv,
+                                  const void *wo, const float *bo, const float *bias_perm, int batch, int H, int W, int ws,
+                                  int shift, int heads, int C, float eps, hipStream_t s) {
+    if (!swin_attn_block_fused_supported(prec, C, heads, ws) || H % ws || W % ws || batch <= 0) return hipErrorInvalidValue;
+    WinGeom gm{H, W, ws, shift, W / ws, (H / ws) * (W / ws), heads};
+    const long total = (long)batch * gm.nW;
+    if (total <= 0 || total > 0x3fffffffL) return hipErrorInvalidValue;
+    constexpr int CG = 3;
+    const int lds = 3 * CG * 4096 + 2 * (64 * 128 + 2 * 32 * 128 + 64) + 4 * C * 4;
+    const float scale2 = 0.17677669529663687f * 1.4426950408889634f;  // 32^-0.5 (SwinAttention.scaling :408) in the log2 domain
+    const dim3 grid((unsigned)((total + 1) / 2)), block(256);
+    static unsigned long long optin[2] = {0, 0};
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    const void *kern = ws == 7 ? (const void *)swin_attn_block_x3_kernel<CG, 7> : (const void *)swin_attn_block_x3_kernel<CG, 0>;
+    unsigned long long &mask = optin[ws == 7 ? 0 : 1];
+    if (!(mask >> (dev & 63) & 1)) {
+        if (hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); e != hipSuccess) return e;
+        mask |= 1ull << (dev & 63);
+    }
+    if (ws == 7)
+        swin_attn_block_x3_kernel<CG, 7><<<grid, block, lds, s>>>(x, g, be, (const char *)wqkv, bqkv, (const char *)wo, bo, bias_perm,
+                                                                   gm, (int)total, scale2, eps);
+    else
+        swin_attn_block_x3_kernel<CG, 0><<<grid, block, lds, s>>>(x, g, be, (const char *)wqkv, bqkv, (const char *)wo, bo, bias_perm,
+                                                                   gm, (int)total, scale2, eps);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // final LayerNorm + AdaptiveAvgPool1d(1) + classifier: one workgroup per image
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void swin_pool_head_kernel(const float *__restrict__ x, const float *__restrict__ g,

@@ -307,6 +307,14 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
             // kernel classes for ocm_prof_begin / ocm_prof_end (tools/bench_swin.py): LayerNorm kernels -> layernorm; the q|k|v
             // projection (fused with layernorm_before or not) -> qkv_gemm; window attention -> attention; attention.output.dense
             // and the patch-merging reduction -> proj_gemm; mlp.fc1 (and the fused LayerNorm + MLP kernel) -> fc1_gemm; mlp.fc2 -> fc2_gemm
+            if (h->fuse_mlp && swin_attn_block_fused_supported(pc, C, heads, ws)) {
+                // stage 0: layernorm_before, q | k | v, window attention, o_proj and the residual in ONE kernel — x is read twice
+                // and written once, no q | k | v or context tensor exists (profiled under the attention class)
+                PROF(OCM_K_ATTN, s);
+                HIP_TRY(launch_swin_attn_block(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), h->ptr<char>(lp.wqkv),
+                                               h->ptr<float>(lp.bqkv), h->ptr<char>(lp.wo), h->ptr<float>(lp.bo),
+                                               h->ptr<float>(lp.bias_perm), batch, H, H, ws, shift, heads, C, eps, s));
+            } else {
             if (h->fuse_mlp && swin_lnqkv_fused_supported(pc, C)) {  // narrow stages: no normalised copy of x in HBM
                 PROF(OCM_K_QKV, s);
                 HIP_TRY(launch_swin_lnqkv(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), h->ptr<char>(lp.wqkv),
@@ -330,6 +338,7 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
                 PROF(OCM_K_PROJ, s);
                 HIP_TRY(swin_linear(pc, w.ctx, Kc, h->ptr<char>(lp.wo), h->ptr<float>(lp.bo), x, x, C, (int)T, C, Kc,
                                          OCM_EPI_BIAS_RESID_F32, s));
+            }
             }
             if (h->fuse_mlp && swin_mlp_fused_supported(pc, C, M)) {  // narrow stages: the hidden activations stay on chip
                 PROF(OCM_K_FC1, s);
@@ -415,6 +424,26 @@ extern "C" int ocm_op_swin_mlp(int32_t precision, float *x, const float *gamma, 
         return fail(OCM_EINVAL, "the fused MLP is built for split-bf16 operands, channels 96 or 128 and hidden = 4 x channels "
                                 "(got precision %d, %d, %d)", precision, channels, hidden);
     HIP_TRY(launch_swin_mlp(pc, x, gamma, beta, w1, b1, w2, b2, (size_t)tokens, channels, hidden, eps, (hipStream_t)stream));
+    return OCM_OK;
+}
+
+extern "C" int ocm_op_swin_attn_block(int32_t precision, float *x, const float *gamma, const float *beta, const void *wqkv,
+                                      const float *bqkv, const void *wo, const float *bo, const float *rel_table, float *scratch,
+                                      int32_t batch, int32_t height, int32_t width, int32_t window, int32_t shift, int32_t heads,
+                                      float eps, void *stream) {
+    if (!x || !gamma || !beta || !wqkv || !bqkv || !wo || !bo || !rel_table || !scratch) return fail(OCM_EINVAL, "null argument");
+    const int pc = precision == OCM_PREC_FP32 ? 1 : precision == OCM_PREC_BF16X3 ? 2 : precision == OCM_PREC_BF16 ? 0 : -1;
+    if (pc < 0) return fail(OCM_EINVAL, "bad precision");
+    if (window < 2 || window > 7 || height <= 0 || width <= 0 || height % window || width % window || batch <= 0 || heads <= 0 ||
+        shift < 0 || shift >= window)
+        return fail(OCM_EINVAL, "bad window geometry");
+    if (!swin_attn_block_fused_supported(pc, heads * 32, heads, window))
+        return fail(OCM_EINVAL, "the fused attention half is built for split-bf16 operands and 3 heads of 32 channels "
+                                "(got precision %d, %d heads)", precision, heads);
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(launch_swin_bias_perm(rel_table, scratch, nullptr, heads, window, s));
+    HIP_TRY(launch_swin_attn_block(pc, x, gamma, beta, wqkv, bqkv, wo, bo, scratch, batch, height, width, window, shift, heads,
+                                   heads * 32, eps, s));
     return OCM_OK;
 }
 
