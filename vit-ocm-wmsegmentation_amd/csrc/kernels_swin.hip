@@ -1122,7 +1122,8 @@ hipError_t launch_swin_mlp(int prec, float *x, const float *g, const float *be, 
 }
 
 // ------------------------------------------------------------------------------------------
-// Attention half of a SwinLayer in one kernel (split-bf16, C = 96: stage 0 of Swin-T)
+// Attention half of a SwinLayer in one kernel (split-bf16; C = 96, stage 0 of Swin-T: all of it; C = 192, stage 1: up to the
+// context, o_proj stays a GEMM)
 //     x += o_proj(window_attention(q | k | v of LayerNorm(x)))      modeling_swin.py SwinLayer.forward :641-666
 // (layernorm_before :641, SwinSelfAttention :430-470 with the relative-position bias :329-370 and the shift mask :584-607,
 // SwinSelfOutput :476-484, the residual :664-666). Unfused, this half streams x, the q | k | v pairs (three times the size
@@ -1139,16 +1140,19 @@ hipError_t launch_swin_mlp(int prec, float *x, const float *g, const float *be, 
 //          the same bits as the unfused path's), V^T read from LDS with its rows in pi order, so that the normalised context
 //          registers ARE the B fragments of y^T (C x 32 tokens) += Wo[:, head] . ctx^T;
 //   * epilogue: + bias + x, fp32, in place (a window's tokens belong to no other window: no other wavefront reads them).
+// FUSE_PROJ false (C = 192: the x fragments take 96 registers, a second set of 96 for y^T does not fit beside them): three
+// chunks per head, the fourth step only waits for the K / V images; the context leaves as pairs (swin_wattn_x3_kernel's
+// stores, V^T rows in natural order) for the o_proj GEMM. Eight wavefronts = four windows per workgroup there.
 // ------------------------------------------------------------------------------------------
-template <int CG, int WS>
-__global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__restrict__ x, const float *__restrict__ gam,
+template <int CG, int WS, int NW, bool FUSE_PROJ>
+__global__ __launch_bounds__(NW * 64, 2) void swin_attn_block_x3_kernel(float *__restrict__ x, const float *__restrict__ gam,
                                                                     const float *__restrict__ bet, const char *__restrict__ wqkv,
                                                                     const float *__restrict__ bqkv, const char *__restrict__ wo,
                                                                     const float *__restrict__ bo,
-                                                                    const float *__restrict__ bias_perm, WinGeom g, int total,
-                                                                    float scale2, float eps) {
-    constexpr int C = CG * 32, HEADS = CG, NW = 4, CH = CG * 4096, NSTAGE = 3, PIECES = 4 * CG, PPW = PIECES / NW;
-    constexpr int NS = 2 * CG, NCH = 4 * HEADS, KV = 64 * 128 + 2 * 32 * 128 + 64;
+                                                                    const float *__restrict__ bias_perm, char *__restrict__ ctx,
+                                                                    WinGeom g, int total, float scale2, float eps) {
+    constexpr int C = CG * 32, HEADS = CG, NWIN = NW / 2, CH = CG * 4096, NSTAGE = 3, PIECES = 4 * CG, PPW = PIECES / NW;
+    constexpr int NS = 2 * CG, KPH = FUSE_PROJ ? 4 : 3, NCH = KPH * HEADS, KV = 64 * 128 + 2 * 32 * 128 + 64;
     static_assert(PIECES % NW == 0, "the wavefronts share the pieces of a chunk evenly");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1158,9 +1162,9 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
     char *Ks = smem + NSTAGE * CH + win * KV;  // K: 64 keys x 128 B (chunks 0..3 hi, 4..7 lo, lds_off swizzle)
     char *Vh = Ks + 64 * 128, *Vl = Vh + 32 * 128;  // V hi / lo: [64 keys][32 dims] row-major, 64-byte rows
     unsigned char *Rg = (unsigned char *)(Vl + 32 * 128);
-    float *bs = (float *)(smem + NSTAGE * CH + 2 * KV);  // bq | bk | bv | bo
+    float *bs = (float *)(smem + NSTAGE * CH + NWIN * KV);  // bq | bk | bv | bo
 
-    int wid = blockIdx.x * 2 + win;
+    int wid = blockIdx.x * NWIN + win;
     const bool wlive = wid < total;  // an odd window count leaves the last workgroup one idle pair (it keeps the barriers)
     wid = min(wid, total - 1);
     const int wlin = wid % g.nW, b = wid / g.nW;
@@ -1172,7 +1176,8 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
     const size_t tok = win_token(g, ws, b, wy, wx, min(p, A - 1));
 
     for (int i = tid; i < 3 * C; i += NW * 64) bs[i] = bqkv[i];
-    for (int i = tid; i < C; i += NW * 64) bs[3 * C + i] = bo[i];
+    if (FUSE_PROJ)
+        for (int i = tid; i < C; i += NW * 64) bs[3 * C + i] = bo[i];
     const bool masked = g.shift > 0 && (wy == g.H / ws - 1 || wx == g.nWx - 1);  // wave-uniform
     if (masked && qt == 0) Rg[lane] = (unsigned char)(lane < A ? win_region(g, ws, wy, wx, lane) : 0);
 
@@ -1192,10 +1197,10 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
     typedef __attribute__((address_space(3))) void *lds_ptr;
     const auto rsq = __builtin_amdgcn_make_buffer_rsrc((void *)wqkv, 0, (unsigned)(3 * C * C * 4), 0x00020000);
     const auto rso = __builtin_amdgcn_make_buffer_rsrc((void *)wo, 0, (unsigned)(C * C * 4), 0x00020000);
-    // chunk j = 4 * head + kind (kind 0 .. 2: rows kind * C + 32 head .. + 31 of Wqkv; kind 3: column group `head` of Wo)
+    // chunk j = KPH * head + kind (kind 0 .. 2: rows kind * C + 32 head .. + 31 of Wqkv; kind 3: column group `head` of Wo)
 #define OCM_AB_DMA(j, st)                                                                                               \
     do {                                                                                                                \
-        const int kind_ = (j) & 3, head_ = (j) >> 2;                                                                    \
+        const int kind_ = (j) % KPH, head_ = (j) / KPH;                                                                 \
         if (kind_ < 3) {                                                                                                \
             _Pragma("unroll") for (int jj = 0; jj < PPW; ++jj)                                                          \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsq, (lds_ptr)(smem + (st) * CH + (jj * NW + wave) * 1024), 16, \
@@ -1246,9 +1251,9 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // rows, parameters and the first two chunks have landed (see swin_mlp_x3_kernel)
 
-    f32x16 Y[CG];
+    f32x16 Y[FUSE_PROJ ? CG : 1];
 #pragma unroll
-    for (int mf = 0; mf < CG; ++mf)
+    for (int mf = 0; mf < (FUSE_PROJ ? CG : 1); ++mf)
 #pragma unroll
         for (int e = 0; e < 16; ++e) Y[mf][e] = 0.f;
     const int pr = pi_row(r);
@@ -1298,7 +1303,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
     const bf16x8 zero8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
 
     for (int head = 0; head < HEADS; ++head) {
-        const int j0 = 4 * head;
+        const int j0 = KPH * head;
         f32x16 S;
         bf16x8 qh[2], ql[2];
         // ---- q
@@ -1310,7 +1315,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
         OCM_AB_NEXT();
         // ---- k -> the window's K image, row p
         OCM_AB_TOP(j0 + 1);
-        OCM_AB_DMA(j0 + 3, si);
+        if (j0 + 3 < NCH) OCM_AB_DMA(j0 + 3, si);
         project(S);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -1322,7 +1327,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
         OCM_AB_NEXT();
         // ---- v -> the window's V images, row p
         OCM_AB_TOP(j0 + 2);
-        if (j0 + 4 < NCH) OCM_AB_DMA(j0 + 4, si);
+        if (j0 + 4 < NCH) OCM_AB_DMA(j0 + 4, si);  // FUSE_PROJ: the next head's q chunk; otherwise its k chunk
         project(S);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -1333,7 +1338,13 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
         }
         OCM_AB_NEXT();
         // ---- scores, softmax, context (swin_wattn_x3_kernel for this wave's query tile), then y^T += Wo[:, head] . ctx^T
-        OCM_AB_TOP(j0 + 3);
+        if constexpr (FUSE_PROJ) {
+            OCM_AB_TOP(j0 + 3);
+        } else {  // no chunk of its own: only the K / V images have to be complete
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         f32x16 S2[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -1378,7 +1389,8 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
         l += __shfl_xor(l, 32, 64);
         // the bias loads above are consumed: the next chunk's DMA is issued only now (hipcc drains every vector-memory
         // operation in front of the first use of an ordinary load's result while an LDS-DMA is in flight)
-        if (j0 + 5 < NCH) OCM_AB_DMA(j0 + 5, si);
+        if constexpr (FUSE_PROJ)
+            if (j0 + 5 < NCH) OCM_AB_DMA(j0 + 5, si);
         f32x16 O;
 #pragma unroll
         for (int e = 0; e < 16; ++e) O[e] = 0.f;
@@ -1397,12 +1409,29 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
                 // V^T rows in pi order: lane 4 q + pp of a 16-lane group addresses key row q, dims 4 swap(pp) .. + 3, so that
                 // column slot i of the group receives dim pi_row(i) and accumulator register e of lane half h holds dim
                 // key_of_reg(e, h): registers 8 s .. 8 s + 7 are the B fragment (k = 16 s + 8 h ..) of the o_proj product
-                const int pp = lane & 3, pps = ((pp & 1) << 1) | (pp >> 1);
+                const int pp = lane & 3, pps = FUSE_PROJ ? ((pp & 1) << 1) | (pp >> 1) : pp;
                 const int voff = (sub * 32 + 16 * s2 + 8 * h + ((lane >> 2) & 3)) * 64 + (16 * ((lane >> 4) & 1) + 4 * pps) * 2;
                 const bf16x8 vh = tr_read8(Vh + voff), vl = tr_read8(Vl + voff);
                 O = mfma32x3(vh, vl, ph, pl, O);
             }
-        {
+        if constexpr (!FUSE_PROJ) {
+            // lane (r, h) holds dims {8 gq + 4 h + e} in fp32: the pair halves go out as four 8-byte pieces per half
+            if (valid && wlive) {
+                const float inv = 1.0f / l;
+                char *dst = ctx + tok * ((size_t)C * 4) + head * 128;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = O[4 * gq + e] * inv;
+                    bf16x4 oh, ol;
+                    split4(o, oh, ol);
+                    char *pd = dst + (8 * gq + 4 * h) * 2;
+                    *(bf16x4 *)pd = oh;
+                    *(bf16x4 *)(pd + 64) = ol;
+                }
+            }
+        } else {
             const float inv = 1.0f / l;
             const char *Wos = smem + sc * CH;
 #pragma unroll
@@ -1423,12 +1452,12 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
                 }
             }
         }
-        OCM_AB_NEXT();
+        if constexpr (FUSE_PROJ) OCM_AB_NEXT();
     }
 #undef OCM_AB_DMA
 #undef OCM_AB_TOP
 #undef OCM_AB_NEXT
-    if (!valid || !wlive) return;
+    if (!FUSE_PROJ || !valid || !wlive) return;
     // y^T: lane (r, h) register 4 gq + e of fragment mf = channel 32 mf + 8 gq + 4 h + e of the lane's token
     float *xo = x + tok * C;
 #pragma unroll
@@ -1444,37 +1473,49 @@ __global__ __launch_bounds__(256, 2) void swin_attn_block_x3_kernel(float *__res
         }
 }
 
+// proj_fused: the whole half in one kernel (C = 96); otherwise (C = 192) the kernel stops at the context pairs
 bool swin_attn_block_fused_supported(int prec, int C, int heads, int ws) {
-    return prec == 2 && C == 96 && heads * 32 == C && ws >= 2 && ws * ws <= 64;
+    return prec == 2 && (C == 96 || C == 192) && heads * 32 == C && ws >= 2 && ws * ws <= 64;
+}
+bool swin_attn_block_proj_fused(int C) { return C == 96; }
+
+template <int CG, int WS, int NW, bool FUSE_PROJ>
+static hipError_t launch_swin_attn_block_t(float *x, const float *g, const float *be, const void *wqkv, const float *bqkv,
+                                           const void *wo, const float *bo, const float *bias_perm, void *ctx, const WinGeom &gm,
+                                           long total, float eps, hipStream_t s) {
+    constexpr int C = CG * 32, NWIN = NW / 2;
+    constexpr int lds = 3 * CG * 4096 + NWIN * (64 * 128 + 2 * 32 * 128 + 64) + 4 * C * 4;
+    static_assert(lds <= 160 * 1024, "LDS");
+    const float scale2 = 0.17677669529663687f * 1.4426950408889634f;  // 32^-0.5 (SwinAttention.scaling :408) in the log2 domain
+    const dim3 grid((unsigned)((total + NWIN - 1) / NWIN)), block(NW * 64);
+    static unsigned long long optin = 0;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+    auto kern = swin_attn_block_x3_kernel<CG, WS, NW, FUSE_PROJ>;
+    if (!(optin >> (dev & 63) & 1)) {
+        if (hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); e != hipSuccess)
+            return e;
+        optin |= 1ull << (dev & 63);
+    }
+    kern<<<grid, block, lds, s>>>(x, g, be, (const char *)wqkv, bqkv, (const char *)wo, bo, bias_perm, (char *)ctx, gm, (int)total,
+                                  scale2, eps);
+    return hipGetLastError();
 }
 
+// ctx: (tokens, C) split pairs, written when the projection is not fused (C = 192); unused otherwise
 hipError_t launch_swin_attn_block(int prec, float *x, const float *g, const float *be, const void *wqkv, const float *bqkv,
-                                  const void *wo, const float *bo, const float *bias_perm, int batch, int H, int W, int ws,
-                                  int shift, int heads, int C, float eps, hipStream_t s) {
+                                  const void *wo, const float *bo, const float *bias_perm, void *ctx, int batch, int H, int W,
+                                  int ws, int shift, int heads, int C, float eps, hipStream_t s) {
     if (!swin_attn_block_fused_supported(prec, C, heads, ws) || H % ws || W % ws || batch <= 0) return hipErrorInvalidValue;
+    if (!swin_attn_block_proj_fused(C) && !ctx) return hipErrorInvalidValue;
     WinGeom gm{H, W, ws, shift, W / ws, (H / ws) * (W / ws), heads};
     const long total = (long)batch * gm.nW;
     if (total <= 0 || total > 0x3fffffffL) return hipErrorInvalidValue;
-    constexpr int CG = 3;
-    const int lds = 3 * CG * 4096 + 2 * (64 * 128 + 2 * 32 * 128 + 64) + 4 * C * 4;
-    const float scale2 = 0.17677669529663687f * 1.4426950408889634f;  // 32^-0.5 (SwinAttention.scaling :408) in the log2 domain
-    const dim3 grid((unsigned)((total + 1) / 2)), block(256);
-    static unsigned long long optin[2] = {0, 0};
-    int dev = 0;
-    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
-    const void *kern = ws == 7 ? (const void *)swin_attn_block_x3_kernel<CG, 7> : (const void *)swin_attn_block_x3_kernel<CG, 0>;
-    unsigned long long &mask = optin[ws == 7 ? 0 : 1];
-    if (!(mask >> (dev & 63) & 1)) {
-        if (hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); e != hipSuccess) return e;
-        mask |= 1ull << (dev & 63);
-    }
-    if (ws == 7)
-        swin_attn_block_x3_kernel<CG, 7><<<grid, block, lds, s>>>(x, g, be, (const char *)wqkv, bqkv, (const char *)wo, bo, bias_perm,
-                                                                   gm, (int)total, scale2, eps);
-    else
-        swin_attn_block_x3_kernel<CG, 0><<<grid, block, lds, s>>>(x, g, be, (const char *)wqkv, bqkv, (const char *)wo, bo, bias_perm,
-                                                                   gm, (int)total, scale2, eps);
-    return hipGetLastError();
+    if (C == 96)
+        return ws == 7 ? launch_swin_attn_block_t<3, 7, 4, true>(x, g, be, wqkv, bqkv, wo, bo, bias_perm, ctx, gm, total, eps, s)
+                       : launch_swin_attn_block_t<3, 0, 4, true>(x, g, be, wqkv, bqkv, wo, bo, bias_perm, ctx, gm, total, eps, s);
+    return ws == 7 ? launch_swin_attn_block_t<6, 7, 8, false>(x, g, be, wqkv, bqkv, wo, bo, bias_perm, ctx, gm, total, eps, s)
+                   : launch_swin_attn_block_t<6, 0, 8, false>(x, g, be, wqkv, bqkv, wo, bo, bias_perm, ctx, gm, total, eps, s);
 }
 
 // ------------------------------------------------------------------------------------------

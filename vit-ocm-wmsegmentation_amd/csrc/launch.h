@@ -166,11 +166,13 @@ hipError_t launch_swin_lnlinear(int prec, const float *x, const float *g, const 
 bool swin_mlp_fused_supported(int prec, int C, int hidden);
 hipError_t launch_swin_mlp(int prec, float *x, const float *g, const float *be, const void *w1, const float *b1,
                            const void *w2, const float *b2, size_t T, int C, int hidden, float eps, hipStream_t s);
-// SwinLayer's attention half in one kernel (split-bf16, C = 96): x += o_proj(window_attention(q | k | v of LayerNorm(x)))
+// SwinLayer's attention half in one kernel (split-bf16): C = 96 x += o_proj(window_attention(q | k | v of LayerNorm(x)));
+// C = 192 ctx = window_attention(q | k | v of LayerNorm(x)) as pairs (swin_attn_block_proj_fused false: o_proj stays a GEMM)
 bool swin_attn_block_fused_supported(int prec, int C, int heads, int ws);
+bool swin_attn_block_proj_fused(int C);
 hipError_t launch_swin_attn_block(int prec, float *x, const float *g, const float *be, const void *wqkv, const float *bqkv,
-                                  const void *wo, const float *bo, const float *bias_perm, int batch, int H, int W, int ws,
-                                  int shift, int heads, int C, float eps, hipStream_t s);
+                                  const void *wo, const float *bo, const float *bias_perm, void *ctx, int batch, int H, int W,
+                                  int ws, int shift, int heads, int C, float eps, hipStream_t s);
 hipError_t launch_swin_pool_head(const float *x, const float *g, const float *be, const float *cw, const float *cb,
                                  float *logits, float *pooled, float *hidden, int batch, int L, int C, int labels,
                                  float eps, hipStream_t s);

@@ -308,12 +308,20 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
             // projection (fused with layernorm_before or not) -> qkv_gemm; window attention -> attention; attention.output.dense
             // and the patch-merging reduction -> proj_gemm; mlp.fc1 (and the fused LayerNorm + MLP kernel) -> fc1_gemm; mlp.fc2 -> fc2_gemm
             if (h->fuse_mlp && swin_attn_block_fused_supported(pc, C, heads, ws)) {
-                // stage 0: layernorm_before, q | k | v, window attention, o_proj and the residual in ONE kernel — x is read twice
-                // and written once, no q | k | v or context tensor exists (profiled under the attention class)
-                PROF(OCM_K_ATTN, s);
-                HIP_TRY(launch_swin_attn_block(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), h->ptr<char>(lp.wqkv),
-                                               h->ptr<float>(lp.bqkv), h->ptr<char>(lp.wo), h->ptr<float>(lp.bo),
-                                               h->ptr<float>(lp.bias_perm), batch, H, H, ws, shift, heads, C, eps, s));
+                // stages 0 and 1: layernorm_before, q | k | v and window attention in ONE kernel — no q | k | v tensor exists; at
+                // 96 channels also o_proj and the residual (x read twice, written once), at 192 the context pairs go to the
+                // o_proj GEMM (profiled under the attention class)
+                {
+                    PROF(OCM_K_ATTN, s);
+                    HIP_TRY(launch_swin_attn_block(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), h->ptr<char>(lp.wqkv),
+                                                   h->ptr<float>(lp.bqkv), h->ptr<char>(lp.wo), h->ptr<float>(lp.bo),
+                                                   h->ptr<float>(lp.bias_perm), w.ctx, batch, H, H, ws, shift, heads, C, eps, s));
+                }
+                if (!swin_attn_block_proj_fused(C)) {
+                    PROF(OCM_K_PROJ, s);
+                    HIP_TRY(swin_linear(pc, w.ctx, Kc, h->ptr<char>(lp.wo), h->ptr<float>(lp.bo), x, x, C, (int)T, C, Kc,
+                                             OCM_EPI_BIAS_RESID_F32, s));
+                }
             } else {
             if (h->fuse_mlp && swin_lnqkv_fused_supported(pc, C)) {  // narrow stages: no normalised copy of x in HBM
                 PROF(OCM_K_QKV, s);
@@ -437,13 +445,19 @@ extern "C" int ocm_op_swin_attn_block(int32_t precision, float *x, const float *
     if (window < 2 || window > 7 || height <= 0 || width <= 0 || height % window || width % window || batch <= 0 || heads <= 0 ||
         shift < 0 || shift >= window)
         return fail(OCM_EINVAL, "bad window geometry");
-    if (!swin_attn_block_fused_supported(pc, heads * 32, heads, window))
-        return fail(OCM_EINVAL, "the fused attention half is built for split-bf16 operands and 3 heads of 32 channels "
+    const int Cn = heads * 32;
+    if (!swin_attn_block_fused_supported(pc, Cn, heads, window))
+        return fail(OCM_EINVAL, "the fused attention half is built for split-bf16 operands and 3 or 6 heads of 32 channels "
                                 "(got precision %d, %d heads)", precision, heads);
     hipStream_t s = (hipStream_t)stream;
+    const int64_t T = (int64_t)batch * height * width;
+    if (T > 0x7fffffffLL) return fail(OCM_EINVAL, "too many tokens");
+    void *ctx = scratch + (size_t)heads * 4096;  // context pairs (6 heads: o_proj is a GEMM of its own)
     HIP_TRY(launch_swin_bias_perm(rel_table, scratch, nullptr, heads, window, s));
-    HIP_TRY(launch_swin_attn_block(pc, x, gamma, beta, wqkv, bqkv, wo, bo, scratch, batch, height, width, window, shift, heads,
-                                   heads * 32, eps, s));
+    HIP_TRY(launch_swin_attn_block(pc, x, gamma, beta, wqkv, bqkv, wo, bo, scratch, ctx, batch, height, width, window, shift,
+                                   heads, Cn, eps, s));
+    if (!swin_attn_block_proj_fused(Cn))
+        HIP_TRY(swin_linear(pc, ctx, Cn, wo, bo, x, x, Cn, (int)T, Cn, Cn, OCM_EPI_BIAS_RESID_F32, s));
     return OCM_OK;
 }
 
