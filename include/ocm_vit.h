@@ -265,13 +265,22 @@ int ocm_op_attention_rows(int32_t precision, const void *q, const void *k, const
  * above), or 128 in OCM_PREC_BF16X3 — the encoder the reference's build_model() constructs
  * (Self-supervised_segmentation/model.py:93-103: embed_dim 384, 3 heads). q / k are then [B*H][n_pad][128] and vt
  * [B*H][128][n_pad] split pairs, ctx [B][N][H*128]. Any other combination returns OCM_EINVAL (an engine handle runs such
- * heads on its generic fp32 attention kernel). */
+ * heads on its generic fp32 attention kernel) — except that ocm_op_qkv_proj_hd with q = k = vt = NULL fills only qkv_f32, for any
+ * head_dim that is a multiple of 8 (the input of ocm_op_attention_generic). */
 int ocm_op_qkv_proj_hd(int32_t precision, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
                        float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, void *stream);
 int ocm_op_attention_hd(int32_t precision, const void *q, const void *k, const void *vt, void *ctx, float *lse2,
                         int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, float scale, void *stream);
 int ocm_op_attention_probs_hd(int32_t precision, const void *q, const void *k, const float *lse2, float *attn,
                               int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, float scale, void *stream);
+
+/* Attention for heads of ANY width (head_dim a multiple of 4, up to 512; at most 8192 tokens) on the fp32 tensor
+ * qkv_f32 [3][B][H][N][head_dim] that ocm_op_qkv_proj_hd writes: plain fp32 FMAs, one wavefront per query row — what an engine
+ * handle runs for head widths the MFMA kernels are not built for, and what the free-standing Attention module
+ * (dino/vision_transformer.py:66-90 accepts any dim / num_heads) calls for them. ctx (optional): [B][N][H*head_dim] in the
+ * operand type of `precision`; attn (optional): fp32 [B][H][N][N]. */
+int ocm_op_attention_generic(int32_t precision, const float *qkv_f32, void *ctx, float *attn, int32_t batch,
+                             int32_t n_tokens, int32_t heads, int32_t head_dim, float scale, void *stream);
 
 /* compute_attention (utils.py:229-235) on device: attn fp32 [B][H][N][N] ->
  * maps fp32 [H][hf*p][wf*p] = nearest-neighbour x p upsample of attn[b, :, query, 1:]. */

@@ -213,6 +213,38 @@ def test_block_level_surface(dev):
     del blk.attn.precision, blk.mlp.precision
 
 
+@pytest.mark.parametrize("dim,heads", [(256, 8), (384, 3), (192, 4), (128, 1)])
+def test_free_standing_attention_accepts_any_head_width(dev, dim, heads):
+    """The reference's Attention (dino/vision_transformer.py:66-90) takes any dim / num_heads; the free-standing mirror runs
+    64-wide heads (and 128-wide ones in split-bf16 precision) on the MFMA kernels and every other width — 32, 48, 128 here — on
+    the generic fp32 attention kernel. Against the reference's arithmetic in float64 on the same parameters."""
+    from vit_ocm_wmsegmentation_amd.dino.vision_transformer import Attention
+    g = torch.Generator().manual_seed(dim + heads)
+    B, N, hd = 2, 37, dim // heads
+    m = Attention(dim, num_heads=heads, qkv_bias=True)
+    with torch.no_grad():
+        m.qkv.weight.copy_(torch.randn(3 * dim, dim, generator=g) * 0.08)
+        m.qkv.bias.copy_(torch.randn(3 * dim, generator=g) * 0.1)
+        m.proj.weight.copy_(torch.randn(dim, dim, generator=g) * 0.06)
+        m.proj.bias.copy_(torch.randn(dim, generator=g) * 0.1)
+    x = torch.randn(B, N, dim, generator=g)
+    xd = x.double()
+    qkv = (xd @ m.qkv.weight.double().t() + m.qkv.bias.double()).reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(qkv[0] @ qkv[1].transpose(-2, -1) * hd ** -0.5, -1)
+    want = (att @ qkv[2]).transpose(1, 2).reshape(B, N, dim) @ m.proj.weight.double().t() + m.proj.bias.double()
+    m = m.to(dev).eval()
+    for prec, tol in (("bf16x3", 2e-4), ("fp32", 2e-5), ("bf16", 8e-2)):  # single bf16: 8 significant bits
+        m.precision = prec
+        y, a, q3 = m(x.to(dev))
+        assert y.shape == (B, N, dim) and a.shape == (B, heads, N, N) and q3.shape == (3, B, heads, N, hd)
+        ey, ea = (y.cpu().double() - want).abs().max().item(), (a.cpu().double() - att).abs().max().item()
+        eq = (q3.cpu().double() - qkv).abs().max().item()
+        print(f"GPUTEST free-standing Attention dim {dim} heads {heads} {prec}: y {ey:.2e} attn {ea:.2e} qkv {eq:.2e}")
+        assert ey <= tol and ea <= tol and eq <= tol, prec
+    with pytest.raises(ValueError):
+        Attention(100, num_heads=5).to(dev)(torch.zeros(1, 4, 100, device=dev))  # head width 20: not a multiple of 8
+
+
 def test_input_variants_and_state_refresh(dev):
     case = CASES["tiny_p8"]
     model = build_module(case, dev)

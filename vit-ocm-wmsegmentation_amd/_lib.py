@@ -131,6 +131,8 @@ SIGNATURES = {
     "ocm_op_qkv_proj_hd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "ocm_op_attention_hd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
     "ocm_op_attention_probs_hd": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _vp]),
+    "ocm_op_attention_generic": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_float, C.c_void_p]),
     "ocm_op_attention_probs": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "ocm_op_attention_rows": (C.c_int, [_i32, _vp, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _f32, _vp]),
     "ocm_op_attention_map": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

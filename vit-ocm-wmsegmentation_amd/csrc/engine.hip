@@ -814,9 +814,12 @@ static int op_qkv_proj(int32_t precision, const void *a, const void *w, const fl
                        float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, void *stream) {
     int pc = 0, rc = prec_of(precision, &pc);
     if (rc) return rc;
-    if (!a || !w || !bias || !q || !k || !vt) return fail(OCM_EINVAL, "null argument");
-    if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    if (head_dim != 64 && !(head_dim == 128 && pc == 2))
+    // operand copies (q, k, vt: all three or none) exist for 64-wide heads and, in split-bf16 precision, for 128-wide ones; without
+    // them the projection only fills the fp32 tensor (any head width that is a multiple of 8: ocm_op_attention_generic reads it)
+    const bool copies = q || k || vt;
+    if (!a || !w || !bias || (copies && (!q || !k || !vt)) || (!copies && !qkv_f32)) return fail(OCM_EINVAL, "null argument");
+    if (batch <= 0 || n_tokens <= 0 || heads <= 0 || head_dim <= 0 || head_dim % 8) return fail(OCM_EINVAL, "bad shape");
+    if (copies && head_dim != 64 && !(head_dim == 128 && pc == 2))
         return fail(OCM_EINVAL, "head_dim %d: operand copies exist for 64-wide heads, and for 128-wide heads in split-bf16 precision", head_dim);
     HIP_TRY(launch_qkv(pc, a, w, bias, q, k, vt, qkv_f32, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, head_dim, true,
                        (hipStream_t)stream));
@@ -868,6 +871,20 @@ extern "C" int ocm_op_attention_hd(int32_t precision, const void *q, const void 
                                    int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, float scale,
                                    void *stream) {
     return op_attention(precision, q, k, vt, ctx, lse2, batch, n_tokens, heads, head_dim, scale, stream);
+}
+
+extern "C" int ocm_op_attention_generic(int32_t precision, const float *qkv_f32, void *ctx, float *attn, int32_t batch,
+                                        int32_t n_tokens, int32_t heads, int32_t head_dim, float scale, void *stream) {
+    int pc = 0, rc = prec_of(precision, &pc);
+    if (rc) return rc;
+    if (!qkv_f32 || (!ctx && !attn)) return fail(OCM_EINVAL, "null argument");
+    if (batch <= 0 || n_tokens <= 0 || heads <= 0 || head_dim <= 0) return fail(OCM_EINVAL, "bad shape");
+    if (head_dim % 4 || head_dim > 512 || n_tokens > 8192 || (pc == 2 && (heads * head_dim) % 32))
+        return fail(OCM_EINVAL, "generic attention: head_dim %d must be a multiple of 4 up to 512, at most 8192 tokens, and "
+                                "heads * head_dim a multiple of 32 for a split-bf16 context", head_dim);
+    HIP_TRY(launch_attention_generic(pc, qkv_f32, ctx, attn, nullptr, 0, nullptr, batch, n_tokens, heads, head_dim, scale,
+                                     (hipStream_t)stream));
+    return OCM_OK;
 }
 
 extern "C" int ocm_op_attention_probs(int32_t precision, const void *q, const void *k, const float *lse2, float *attn,

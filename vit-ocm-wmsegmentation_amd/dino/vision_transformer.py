@@ -126,23 +126,33 @@ class Attention(nn.Module):
         lib, pc = _lib.load(), _module_prec(self)
         B, N, Cd = x.shape
         H = self.num_heads
-        if Cd != H * 64:
-            raise ValueError("the HIP attention kernels need head_dim == 64")
+        if Cd % H or (Cd // H) % 8:
+            raise ValueError(f"dim {Cd} / num_heads {H}: the HIP kernels need a head width that is a multiple of 8")
+        hd = Cd // H
+        # 64-wide heads, and 128-wide ones in split-bf16 precision (model.py:93-103), run the MFMA attention kernels; any other
+        # width (the reference accepts every dim / num_heads, :66-90) the generic fp32 kernel on the fp32 qkv tensor
+        mfma = hd == 64 or (hd == 128 and pc == _lib.OCM_PREC_BF16X3)
         x32 = _f32c(x).reshape(B * N, Cd)
         dev, npad, adt = x32.device, lib.ocm_n_pad_prec(pc, N), _ACT_DTYPE[pc]
         with torch.cuda.device(dev):
             a = to_operand(x32, pc)
-            q = torch.empty((B * H, npad, 64), dtype=adt, device=dev)
-            k = torch.empty_like(q)
-            vt = torch.zeros((B * H, 64, npad), dtype=adt, device=dev)
-            qkv = torch.empty((3, B, H, N, 64), dtype=torch.float32, device=dev)
-            _lib.check(lib.ocm_op_qkv_proj(pc, _p(a), _p(self._w[0].get(self.qkv.weight, pc)), _p(_bias_or_zeros(self.qkv)),
-                                           _p(q), _p(k), _p(vt), _p(qkv), B, N, H, _stream()))
+            qkv = torch.empty((3, B, H, N, hd), dtype=torch.float32, device=dev)
             ctx = torch.empty((B * N, Cd), dtype=adt, device=dev)
-            lse = torch.empty((B * H, N), dtype=torch.float32, device=dev)
-            _lib.check(lib.ocm_op_attention(pc, _p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, float(self.scale), _stream()))
             attn = torch.empty((B, H, N, N), dtype=torch.float32, device=dev)
-            _lib.check(lib.ocm_op_attention_probs(pc, _p(q), _p(k), _p(lse), _p(attn), B, N, H, float(self.scale), _stream()))
+            wq, bq = _p(self._w[0].get(self.qkv.weight, pc)), _p(_bias_or_zeros(self.qkv))
+            if mfma:
+                q = torch.empty((B * H, npad, hd), dtype=adt, device=dev)
+                k = torch.empty_like(q)
+                vt = torch.zeros((B * H, hd, npad), dtype=adt, device=dev)
+                _lib.check(lib.ocm_op_qkv_proj_hd(pc, _p(a), wq, bq, _p(q), _p(k), _p(vt), _p(qkv), B, N, H, hd, _stream()))
+                lse = torch.empty((B * H, N), dtype=torch.float32, device=dev)
+                _lib.check(lib.ocm_op_attention_hd(pc, _p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, hd, float(self.scale),
+                                                   _stream()))
+                _lib.check(lib.ocm_op_attention_probs_hd(pc, _p(q), _p(k), _p(lse), _p(attn), B, N, H, hd, float(self.scale),
+                                                         _stream()))
+            else:
+                _lib.check(lib.ocm_op_qkv_proj_hd(pc, _p(a), wq, bq, None, None, None, _p(qkv), B, N, H, hd, _stream()))
+                _lib.check(lib.ocm_op_attention_generic(pc, _p(qkv), _p(ctx), _p(attn), B, N, H, hd, float(self.scale), _stream()))
             y = torch.empty((B * N, Cd), dtype=torch.float32, device=dev)
             _lib.check(lib.ocm_op_linear(pc, _p(ctx), _p(self._w[1].get(self.proj.weight, pc)), _p(_bias_or_zeros(self.proj)),
                                          None, _p(y), B * N, Cd, Cd, _lib.OCM_EPI_BIAS_F32, _stream()))
