@@ -432,6 +432,11 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             if (K >= 1024 && N % 64 == 0) return launch_gemm_dma<Cfg64x64, E, 4>(a, K, w, K, M, N, K, epi, s);
             if (N % 128 == 0) return launch_gemm_dma<Cfg64x128w, E, OCM_SMALLM_STAGES>(a, K, w, K, M, N, K, epi, s);
         }
+        // mlp.fc1 at K = 384 and tens of thousands of rows (the 4096^2 slab sweep: 48 k rows; Swin-T stage 2 at batch 256: 50 k):
+        // the same 256 x 256 tile although its K loop is only twelve steps (round 4, knob 0 = 19 against the 128 x 128 tile,
+        // alternating on one box: slab sweep 534.6 -> 530.6 ms, Swin-T 10.35 -> 10.27 ms; attn.qkv LOSES on it: 534.6 -> 558 ms)
+        if (K == 384 && N % 256 == 0 && N >= 1024 && M >= 16384 && OCM_KNOB(0) != 20)
+            return launch_gemm_dma<Cfg256x256m16, E, 2>(a, K, w, K, M, N, K, epi, s);
         if (big_tiles_pay(M, N, K))  // ViT-B at 384^2: 256x256 tiles, one 8-wave workgroup per CU (fc1 1020 -> 944 us), on
             // v_mfma_f32_16x16x32_bf16 since round 4 (B = 128, alternating runs: fc1 965 -> 870 us, fc2 903 -> 820, proj 281 -> 256)
             return launch_gemm_dma<Cfg256x256m16, E, 2>(a, K, w, K, M, N, K, epi, s);
@@ -453,7 +458,10 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             // so does mlp.fc1 at 48 k rows: slab sweep 530 -> 533 ms)
             // (round 4, on the 16 x 16 MFMA shape: at 48 k rows too — slab sweep 541.8 -> 538.7 ms against the four-wave tile, which
             // on the 32 x 32 shape had been the faster one there; knob 0 = 17: the four-wave tile on the 16 x 16 shape, 542.9 ms)
-            if (N >= 1024 && OCM_KNOB(0) != 17) return launch_gemm_dma<Cfg128x128q16, E, 2>(a, K, w, K, M, N, K, epi, s);
+            // (round 4: narrower outputs that reach this branch — Swin-T stages 2 - 3, N = 384 / 768 at 50 k / 12 k rows — also
+            // run faster on it than on the four-wave 32 x 32-shape tile: Swin-T at batch 256 10.35 -> 10.17 ms, knob 0 = 13;
+            // knob 0 = 21 keeps the four-wave tile for them)
+            if ((N >= 1024 || OCM_KNOB(0) != 21) && OCM_KNOB(0) != 17) return launch_gemm_dma<Cfg128x128q16, E, 2>(a, K, w, K, M, N, K, epi, s);
             if (OCM_KNOB(0) == 17) return launch_gemm_dma<Cfg128x128m16, E, 2>(a, K, w, K, M, N, K, epi, s);
             return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
         }
