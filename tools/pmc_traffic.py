@@ -25,7 +25,7 @@ CLASSES = {
     "slab_bf16x3": {
         "attention": "attn_fwd_x3_dma_kernel<true, 8, 2,",
         "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2, 0>, sp32, false, 48, 3, EpiLinear<1",  # 128 x 192 tiles, LayerNorm kernels at this size
-        "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 4, 1>, sp32, false, 12, 2, EpiLinear<2",  # round 4: eight waves, 16 x 16 MFMA shape at every row count
+        "fc1_gemm": "gemm_dma_kernel<GemmCfg<256, 256, 2, 4, 1>, sp32, false, 12, 2, EpiLinear<2",  # round 4: 256 x 256 tiles at K = 384 from 16 k rows
     },
 }
 
