@@ -1260,10 +1260,11 @@ __global__ __launch_bounds__(NW * 64, 2) void swin_attn_block_x3_kernel(float *_
     int sc = 0, si = NSTAGE - 1;
     // top of step j: own pieces of chunk j have landed (chunk j + 1 may still be on its way), everybody's have after the
     // barrier, and everybody is past the stage that chunk j + 2 goes into
-#define OCM_AB_TOP(j)                                                                  \
+    // (EXTRA: vector-memory loads issued between chunk j's DMA and chunk j + 1's, or after both — the head's eight bias loads)
+#define OCM_AB_TOP(j, EXTRA)                                                           \
     do {                                                                               \
         if ((j) + 1 < NCH)                                                             \
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");                 \
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW + (EXTRA)) : "memory");       \
         else                                                                           \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                           \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             \
@@ -1306,15 +1307,24 @@ __global__ __launch_bounds__(NW * 64, 2) void swin_attn_block_x3_kernel(float *_
         const int j0 = KPH * head;
         f32x16 S;
         bf16x8 qh[2], ql[2];
+        // the head's relative-position bias (lane / register order of the score tiles), requested a whole head ahead of its use
+        f32x4 bv[2][4];
+        {
+            const float *bq = bias_perm + ((size_t)head * 2 + qt) * 64 * 32 + lane * 4;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) bv[sub][e4] = *(const f32x4 *)(bq + (sub * 4 + e4) * 256);
+        }
         // ---- q
-        OCM_AB_TOP(j0);
+        OCM_AB_TOP(j0, 8);
         OCM_AB_DMA(j0 + 2, si);
         project(S);
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) biased_pair(S, bs + head * 32, s2, qh[s2], ql[s2]);
         OCM_AB_NEXT();
         // ---- k -> the window's K image, row p
-        OCM_AB_TOP(j0 + 1);
+        OCM_AB_TOP(j0 + 1, 8);
         if (j0 + 3 < NCH) OCM_AB_DMA(j0 + 3, si);
         project(S);
 #pragma unroll
@@ -1326,7 +1336,7 @@ __global__ __launch_bounds__(NW * 64, 2) void swin_attn_block_x3_kernel(float *_
         }
         OCM_AB_NEXT();
         // ---- v -> the window's V images, row p
-        OCM_AB_TOP(j0 + 2);
+        OCM_AB_TOP(j0 + 2, 0);
         if (j0 + 4 < NCH) OCM_AB_DMA(j0 + 4, si);  // FUSE_PROJ: the next head's q chunk; otherwise its k chunk
         project(S);
 #pragma unroll
@@ -1339,7 +1349,7 @@ __global__ __launch_bounds__(NW * 64, 2) void swin_attn_block_x3_kernel(float *_
         OCM_AB_NEXT();
         // ---- scores, softmax, context (swin_wattn_x3_kernel for this wave's query tile), then y^T += Wo[:, head] . ctx^T
         if constexpr (FUSE_PROJ) {
-            OCM_AB_TOP(j0 + 3);
+            OCM_AB_TOP(j0 + 3, 0);
         } else {  // no chunk of its own: only the K / V images have to be complete
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1357,17 +1367,15 @@ __global__ __launch_bounds__(NW * 64, 2) void swin_attn_block_x3_kernel(float *_
                 S2[sub] = mfma32x3(kh, kl, qh[s], ql[s], S2[sub]);
             }
         }
-        const float *bq = bias_perm + ((size_t)head * 2 + qt) * 64 * 32 + lane * 4;
         float mx = -INFINITY;
         const int myreg = masked ? Rg[min(p, A - 1)] : 0;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
-                const f32x4 bv = *(const f32x4 *)(bq + (sub * 4 + e4) * 256);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = fmaf(S2[sub][e4 * 4 + e], scale2, bv[e]);
+                    float v = fmaf(S2[sub][e4 * 4 + e], scale2, bv[sub][e4][e]);
                     if (masked) {
                         const int jk = sub * 32 + key_of_reg(e4 * 4 + e, h);
                         if (jk < A && Rg[jk] != myreg) v += -100.0f * 1.4426950408889634f;
