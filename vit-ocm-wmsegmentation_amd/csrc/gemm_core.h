@@ -52,7 +52,11 @@ struct GemmCfg {
     static constexpr int BM = BM_, BN = BN_, WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, MF16 = MF16_;
     static constexpr int NT = WAVES_M * WAVES_N * OCM_WAVE;
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
-    static constexpr int TM = WM / 32, TN = WN / 32;
+    // HALF (16 x 16 MFMA shape, LDS-DMA loop only): a wave's LAST 32 x 32 tile is only its upper 16 rows — BM = (TM - 1) * RB + 16 *
+    // WAVES_M, the half tiles of the waves forming one band of 16 * WAVES_M rows at the bottom of the block tile. 160-row tiles
+    // (TM = 3: two full tiles and a half) exist for row counts whose 128-row tiling leaves a nearly empty last round of workgroups.
+    static constexpr int HALF = (WM % 32 == 16) ? 1 : 0;
+    static constexpr int TM = (WM + 31) / 32, TN = WN / 32;
     static constexpr int A_CH = BM * 8 / NT, B_CH = BN * 8 / NT;  // 16-B chunks / thread / K-step
     static constexpr int LDS_BYTES = 2 * (BM + BN) * 128;
     // A wave's 32x32 tiles are INTERLEAVED with the other waves': tile (i, j) of wave (wm, wn) sits at
@@ -60,8 +64,8 @@ struct GemmCfg {
     // of all waves together cover a contiguous band of RB (CB) rows (columns) — the unit the epilogue
     // stages through LDS when the whole fp32 tile does not fit.
     static constexpr int RB = 32 * WAVES_M, CB = 32 * WAVES_N;
-    static_assert(WM % 32 == 0 && WN % 32 == 0, "wave tile must be a multiple of 32x32");
-    static_assert((BM * 8) % NT == 0 && (BN * 8) % NT == 0, "staging must divide evenly");
+    static_assert((WM % 32 == 0 || (HALF && MF16_)) && WN % 32 == 0, "wave tile must be a multiple of 32x32 (or end in a 16-row half tile)");
+    static_assert(HALF || ((BM * 8) % NT == 0 && (BN * 8) % NT == 0), "staging must divide evenly");
     static_assert(NT % 8 == 0, "a thread keeps one chunk column");
 };
 
@@ -124,8 +128,9 @@ struct RowLoader {
 // One K step of MFMAs on the LDS tiles at Ab / Bb (already offset to the wave's rows).
 template <class Cfg, class E, bool SWAP>
 __device__ __forceinline__ void mma_step(const char *Ab, const char *Bb, int r, int h,
-                                         f32x16 (&acc)[Cfg::TM][Cfg::TN]) {
+                                         f32x16 (&acc)[Cfg::TM][Cfg::TN], int wm = 0) {
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
+    static_assert(!Cfg::HALF || (Elem<E>::MODE == 2 && Cfg::MF16 && !SWAP), "half tiles exist on the 16 x 16 shape only");
     if constexpr (Elem<E>::MODE == 2 && Cfg::MF16) {
         // split-bf16 on 16x16x32: lane (row r & 15 of a 16-row half, k chunk g) reads hi chunk g / lo chunk 4 + g of its row —
         // the whole K step in one instruction per (half, part); twelve MFMAs per 32 x 32 tile and step, four accumulators
@@ -135,6 +140,14 @@ __device__ __forceinline__ void mma_step(const char *Ab, const char *Bb, int r, 
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int ra = 0; ra < 2; ++ra) {
+                if (Cfg::HALF && i == TM - 1) {  // Ab = tile rows wm * 32: the half band starts at (TM - 1) * RB, this wave's rows at wm * 16 in it
+                    if (ra == 0) {
+                        const char *Ah = Ab + ((TM - 1) * Cfg::RB - wm * 16) * 128;
+                        ah[i][0] = *(const bf16x8 *)(Ah + lds_off(r16, g));
+                        al[i][0] = *(const bf16x8 *)(Ah + lds_off(r16, 4 + g));
+                    }
+                    continue;
+                }
                 ah[i][ra] = *(const bf16x8 *)(Ab + i * Cfg::RB * 128 + lds_off(ra * 16 + r16, g));
                 al[i][ra] = *(const bf16x8 *)(Ab + i * Cfg::RB * 128 + lds_off(ra * 16 + r16, 4 + g));
             }
@@ -150,7 +163,7 @@ __device__ __forceinline__ void mma_step(const char *Ab, const char *Bb, int r, 
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < ((Cfg::HALF && i == TM - 1) ? 2 : 4); ++q) {
                     // sub-tile q: register-indexed half q >> 1, lane-indexed half q & 1. Normal: registers = rows (A), lanes =
                     // columns (B); SWAP: registers = n (B rows as the first operand), lanes = m
                     f32x4_t c = __builtin_shufflevector(acc[i][j], acc[i][j], 0, 1, 2, 3);
@@ -234,6 +247,7 @@ __device__ __forceinline__ void gemm_mainloop(const ALoad &al, const E *__restri
                                               int M, int N, int K, char *smem, f32x16 (&acc)[Cfg::TM][Cfg::TN],
                                               const float *__restrict__ bias) {
     typedef typename Elem<E>::Chunk Chunk;
+    static_assert(!Cfg::HALF, "half tiles exist on the LDS-DMA loop only");
     constexpr int KROW = Elem<E>::KROW;
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT;
     constexpr int A_CH = Cfg::A_CH, B_CH = Cfg::B_CH, TM = Cfg::TM, TN = Cfg::TN;
@@ -452,6 +466,18 @@ __device__ __forceinline__ void dma_rows(__amdgpu_buffer_rsrc_t rs, char *img, c
 #endif
 }
 
+// the same with an explicit LDS piece index per instruction
+template <int CNT, int AUX = 0>
+__device__ __forceinline__ void dma_pieces(__amdgpu_buffer_rsrc_t rs, char *img, const int (&voff)[CNT], const int (&piece)[CNT],
+                                           int soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(3))) void *lds_ptr;
+#pragma unroll
+    for (int j = 0; j < CNT; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(img + piece[j] * 1024), 16, voff[j], soff, 0, AUX);
+#endif
+}
+
 // A_AUX: cache-policy bits of the A operand's DMA loads (2 = nt: streamed activations should not evict the weights)
 template <class Cfg, class E, bool SWAP, int KSTEPS, int NSTAGE, int A_AUX = 0>
 __device__ __forceinline__ void gemm_mainloop_dma(const E *__restrict__ A, int64_t lda, const E *__restrict__ W,
@@ -459,9 +485,12 @@ __device__ __forceinline__ void gemm_mainloop_dma(const E *__restrict__ A, int64
                                                   f32x16 (&acc)[Cfg::TM][Cfg::TN], const float *__restrict__ bias) {
     constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, NW = NT / 64;
     constexpr int TM = Cfg::TM, TN = Cfg::TN;
-    constexpr int A_I = BM / 8 / NW, B_I = BN / 8 / NW, LPS = A_I + B_I;  // DMA instructions per wave per K step
+    // DMA instructions per wave per K step. A tile whose row count is not a multiple of 8 NW (HALF: 160 rows = 20 pieces on eight
+    // waves) gives every wave ceil(pieces / NW) instructions: the surplus ones repeat the piece of wave - (pieces % NW) — the same
+    // bytes to the same LDS rows twice, a benign duplicate that keeps the counted vmcnt waits the same in every wave
+    constexpr int A_P = BM / 8, A_I = (A_P + NW - 1) / NW, B_I = BN / 8 / NW, LPS = A_I + B_I;
     constexpr int STAGE = (BM + BN) * 128, D = NSTAGE - 1;
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "each wave fills whole groups of 8 rows");
+    static_assert(BM % 8 == 0 && BN % (8 * NW) == 0 && (A_P % NW == 0 || 2 * (A_P % NW) >= NW), "each wave fills whole groups of 8 rows");
     static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 LDS stages");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -479,9 +508,13 @@ __device__ __forceinline__ void gemm_mainloop_dma(const E *__restrict__ A, int64
     const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)W + (int64_t)n0 * ldw * esz), 0,
                                                        bound(N - n0, ldw * esz), 0x00020000);
     int voffA[A_I], voffB[B_I];
+    int pieceA[A_I];  // LDS piece (8 rows) that instruction j of this wave fills
 #pragma unroll
     for (int j = 0; j < A_I; ++j) {
-        const int rho = (j * NW + wave) * 8 + (lane >> 3);
+        int pc = j * NW + wave;
+        if (pc >= A_P) pc -= A_P % NW;  // surplus instruction of the last round: a duplicate (see above)
+        pieceA[j] = pc;
+        const int rho = pc * 8 + (lane >> 3);
         voffA[j] = rho * (int)(lda * esz) + (((lane & 7) ^ ((rho >> 1) & 7)) << 4);
     }
 #pragma unroll
@@ -493,12 +526,12 @@ __device__ __forceinline__ void gemm_mainloop_dma(const E *__restrict__ A, int64
 #define OCM_DMA_ISSUE(t, buf)                                                   \
     do {                                                                        \
         char *st_ = smem + (buf) * STAGE;                                       \
-        dma_rows<A_I, NW, A_AUX>(rsA, st_, voffA, wave, (t) * 128);             \
+        dma_pieces<A_I, A_AUX>(rsA, st_, voffA, pieceA, (t) * 128);             \
         dma_rows<B_I, NW>(rsB, st_ + BM * 128, voffB, wave, (t) * 128);         \
     } while (0)
     auto compute = [&](int buf) {
         const char *st = smem + buf * STAGE;
-        mma_step<Cfg, E, SWAP>(st + (wm * 32) * 128, st + BM * 128 + (wn * 32) * 128, r, h, acc);
+        mma_step<Cfg, E, SWAP>(st + (wm * 32) * 128, st + BM * 128 + (wn * 32) * 128, r, h, acc, wm);
     };
 
     // accumulators start at the bias (see gemm_mainloop): the bias loads are issued first (oldest), the prologue
@@ -618,11 +651,12 @@ __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::T
         for (int i = 0; i < Cfg::TM; ++i)
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) {
-                const int tm = (i * Cfg::WAVES_M + wm) * 32, tn = (j * Cfg::WAVES_N + wn) * 32;
+                const bool half = Cfg::HALF && i == Cfg::TM - 1;  // the wave's half tile: 16 rows at wm * 16 of the bottom band
+                const int tm = half ? (Cfg::TM - 1) * Cfg::RB + wm * 16 : (i * Cfg::WAVES_M + wm) * 32, tn = (j * Cfg::WAVES_N + wn) * 32;
                 // normal: lane -> column n, registers -> rows m.  swapped: lane -> m, registers -> n.
                 const int row0 = SWAP ? tn : tm, col0 = SWAP ? tm : tn;
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
+                for (int e = 0; e < (half ? 8 : 16); ++e)
                     C[(row0 + acc_rpos<ACCL>(e, lane)) * COLS + col0 + acc_cpos<ACCL>(e, lane)] = acc[i][j][e];
             }
         STAMP(2);
@@ -637,18 +671,25 @@ __device__ __forceinline__ void run_epilogue(const f32x16 (&acc)[Cfg::TM][Cfg::T
         for (int i = 0; i < Cfg::TM; ++i) {
             if (NBUF == 1 && i) lds_barrier();  // the band's readers are done
             float *C = (float *)(smem + (i % NBUF) * PASS);
+            const bool half = Cfg::HALF && i == Cfg::TM - 1;  // the bottom band of 16-row half tiles: RB / 2 rows
             if (active)
 #pragma unroll
             for (int j = 0; j < Cfg::TN; ++j) {
                 const int col0 = (j * Cfg::WAVES_N + wn) * 32;
 #pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    C[(wm * 32 + acc_rpos<ACCL>(e, lane)) * Cfg::BN + col0 + acc_cpos<ACCL>(e, lane)] = acc[i][j][e];
+                for (int e = 0; e < (half ? 8 : 16); ++e)
+                    C[(wm * (half ? 16 : 32) + acc_rpos<ACCL>(e, lane)) * Cfg::BN + col0 + acc_cpos<ACCL>(e, lane)] = acc[i][j][e];
             }
             lds_barrier();  // also orders pass i-2's reads of this buffer before pass i's writes (see above)
-            if (active) epi.template run<PassCfg<Cfg::RB, Cfg::BN, Cfg::NT>>((const float *)C, m0 + i * Cfg::RB, n0, rowtab + i * Cfg::RB, coltab);
+            if (active) {
+                if (half)
+                    epi.template run<PassCfg<Cfg::RB / 2, Cfg::BN, Cfg::NT>>((const float *)C, m0 + i * Cfg::RB, n0, rowtab + i * Cfg::RB, coltab);
+                else
+                    epi.template run<PassCfg<Cfg::RB, Cfg::BN, Cfg::NT>>((const float *)C, m0 + i * Cfg::RB, n0, rowtab + i * Cfg::RB, coltab);
+            }
         }
     } else {
+        static_assert(!Cfg::HALF, "half tiles: normal orientation only");
         constexpr int PASS = Cfg::CB * Cfg::BM * 4;  // one band of CB feature rows of the transposed tile
         static_assert(PASS <= LDS_AVAIL, "a column band must fit the operand LDS");
         constexpr int NBUF = 2 * PASS <= LDS_AVAIL ? 2 : 1;

@@ -32,6 +32,9 @@ typedef GemmCfg<128, 128, 2, 4> Cfg128x128q;
 // ... and on v_mfma_f32_16x16x32_bf16 for the split-bf16 LDS-DMA launches of that tile (gemm_core.h: GemmCfg::MF16)
 typedef GemmCfg<128, 128, 2, 4, 1> Cfg128x128q16;
 typedef GemmCfg<128, 128, 2, 2, 1> Cfg128x128m16;  // development A/B (four waves: the tile of forwards of 32 k rows and more)
+// 160 rows: two full 32-row tiles and a 16-row half tile per wave row (gemm_core.h: GemmCfg::HALF). At 12 608 rows (ViT-S/16, B = 64)
+// mlp.fc1 is 79 x 12 = 948 of these = 1.85 rounds of the 512 two-per-CU slots instead of 1 188 tiles of 128 x 128 = 2.32
+typedef GemmCfg<160, 128, 2, 4, 1> Cfg160x128q16;
 typedef GemmCfg<256, 256, 2, 4, 1> Cfg256x256m16;  // ViT-B sizes
 typedef GemmCfg<64, 128, 2, 2> Cfg64x128;
 // the same tile on eight wavefronts (32 x 32 each) for the one-tile-per-call forwards: with ONE workgroup per CU a lone wave per
@@ -452,7 +455,7 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             const double e192 = (double)t192 / (256.0 * ((t192 + 255) / 256)), e128 = (double)t128 / (512.0 * ((t128 + 511) / 512));
             if (t128 < 512 || e192 > 1.1 * e128) return launch_gemm_dma<Cfg128x192, E, 3>(a, K, w, K, M, N, K, epi, s);
         }
-        if (N % 128 == 0 && (long)((M + 127) / 128) * (N / 128) >= 512) {
+        if (const long t128s = (long)((M + 127) / 128) * (N / 128); N % 128 == 0 && t128s >= 512) {
             // wide outputs (mlp.fc1): the same tile on eight wavefronts, four per SIMD with two workgroups per CU (58.0 -> 56.2 us
             // in the forward on one box, 53.0 -> 51.8 on another; the N = 384 layers lose on it: fc2 56 -> 62, proj 26 -> 27, and
             // so does mlp.fc1 at 48 k rows: slab sweep 530 -> 533 ms)
@@ -461,6 +464,13 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             // (round 4: narrower outputs that reach this branch — Swin-T stages 2 - 3, N = 384 / 768 at 50 k / 12 k rows — also
             // run faster on it than on the four-wave 32 x 32-shape tile: Swin-T at batch 256 10.35 -> 10.17 ms, knob 0 = 13;
             // knob 0 = 21 keeps the four-wave tile for them)
+            if constexpr (MODE == 2 || MODE == 3) {  // (the activation-output epilogues: any tile height)
+                // 160-row tiles when they fill the two-per-CU slots better: rounds of 512 workgroups, last one counted by its fill
+                const long t160 = (long)((M + 159) / 160) * (N / 128);
+                const double e128 = (double)t128s / (512.0 * ((t128s + 511) / 512)), e160 = (double)t160 / (512.0 * ((t160 + 511) / 512));
+                if (N >= 1024 && K == 384 && e160 > 1.1 * e128 && OCM_KNOB(0) != 22)
+                    return launch_gemm_dma<Cfg160x128q16, E, 2>(a, K, w, K, M, N, K, epi, s);
+            }
             if ((N >= 1024 || OCM_KNOB(0) != 21) && OCM_KNOB(0) != 17) return launch_gemm_dma<Cfg128x128q16, E, 2>(a, K, w, K, M, N, K, epi, s);
             if (OCM_KNOB(0) == 17) return launch_gemm_dma<Cfg128x128m16, E, 2>(a, K, w, K, M, N, K, epi, s);
             return launch_gemm_dma<Cfg128x128, E, 2>(a, K, w, K, M, N, K, epi, s);
