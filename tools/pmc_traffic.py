@@ -13,7 +13,7 @@ import sys
 CLASSES = {
     "bf16x3": {
         # round 4: GemmCfg carries the MFMA shape as its fifth argument (1 = v_mfma_f32_16x16x32_bf16: fc1 / qkv)
-        "fc1_gemm": "gemm_dma_kernel<GemmCfg<128, 128, 2, 4, 1>, sp32, false, 12,",
+        "fc1_gemm": "gemm_dma_kernel<GemmCfg<160, 128, 2, 4, 1>, sp32, false, 12,",  # 160-row tiles (GemmCfg::HALF) at this row count
         # round 3: LayerNorm folded into its consumer -> attn.proj / mlp.fc2 on 128 x 192 LDS-DMA tiles (x, split(x), row sums)
         "fc2_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2, 0>, sp32, false, 48,",
         "proj_gemm": "gemm_dma_kernel<GemmCfg<128, 192, 4, 2, 0>, sp32, false, 12,",
