@@ -61,7 +61,10 @@ def test_layernorm_split_out(lib, dev, rows, dim):
 
 
 # The shapes reach every split-bf16 GEMM the BASELINE configurations dispatch (gemm_kernels.h::launch_linear_epi):
-#   (12608, 1536, 384)  config 2 fc1: 1188 tiles, N >= 1024 -> gemm_dma_kernel<128x128, eight waves>, two workgroups per CU
+#   (12608, 1536, 384)  config 2 fc1: 1188 tiles, N >= 1024 -> gemm_dma_kernel<128x128, eight waves>, two workgroups per CU; with an
+#                       activation output (epilogues 2 / 3) 948 tiles of 160 x 128 since round 4 (GemmCfg::HALF: a 16-row half tile
+#                       per wave row) — (12609, ...) leaves ONE valid row in the last block's half band, (20000, 1024, 384) is
+#                       125 full blocks of 160 rows
 #   (12608, 384, *)     config 2 proj / fc2: gemm_dma_kernel<128x192> on a three-stage ring
 #   (32768, 1024, 768)  config 3: 512 tiles of 256x256 -> gemm_dma_kernel<256x256>, banded epilogue
 #   (24576, 384, 1536)  config 4 fc2 (48 K steps) -> gemm_dma_kernel<128x192> as well since round 3
@@ -71,7 +74,8 @@ def test_layernorm_split_out(lib, dev, rows, dim):
 #   (6000, 288 / 96, 96), (5000, 576 / 192, *): Swin-T's narrow stages in split-bf16 mode -> gemm_dma_kernel<128x96> / <128x192>
 @pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (12608, 1536, 384), (333, 384, 1536), (70, 96, 192),
                                    (12608, 384, 384), (64, 192, 64), (32768, 1024, 768), (24576, 384, 1536),
-                                   (6000, 288, 96), (6000, 96, 384), (5000, 576, 192), (5000, 192, 768), (16384, 512, 384)])
+                                   (6000, 288, 96), (6000, 96, 384), (5000, 576, 192), (5000, 192, 768), (16384, 512, 384),
+                                   (12609, 1536, 384), (20000, 1024, 384)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_linear_x3(lib, dev, M, N, K, epi):
     a = _rand((M, K), dev, 40)

@@ -421,6 +421,7 @@ static hipError_t launch_linear_epi(const E *a, const E *w, const Epi &epi, int 
             case 13: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128q16, E, 2>(a, K, w, K, M, N, K, epi, s); break;
             case 14: if (N % 128 == 0) return launch_gemm_dma<Cfg128x128m16, E, 2>(a, K, w, K, M, N, K, epi, s); break;
             case 19: if (N % 256 == 0 && N >= 1024 && M >= 16384) return launch_gemm_dma<Cfg256x256m16, E, 2>(a, K, w, K, M, N, K, epi, s); break;
+            case 23: if (N % 128 == 0 && M >= 4096) return launch_gemm_dma<Cfg160x128q16, E, 2>(a, K, w, K, M, N, K, epi, s); break;
             default: break;
         }
 #endif
