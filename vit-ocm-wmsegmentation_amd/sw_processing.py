@@ -244,7 +244,11 @@ class SlidingWindowAttention:
                                better; otherwise 128 x 128 tiles, two per CU.
         The plan with the lowest charge wins (ties: fewer forwards). Measured on one MI355X (split-bf16, 900 windows of 2305
         tokens): 16 .. 32 windows per forward all land within 522 .. 536 ms per sweep; a plan that spills fc1 into a
-        nearly empty extra round (22 windows: 9.1 rounds) costs 3-7 %."""
+        nearly empty extra round (22 windows: 9.1 rounds) costs 3-7 %.
+        (Round 4: from 16 384 rows mlp.fc1 runs 256 x 256 tiles, one per CU. The charge still prices the 128 x 128 grid on
+        purpose: priced on the 256-row grid the model prefers 50 forwards of 18 windows, which MEASURES 533.1 ms per sweep
+        against 528.9 ms for the 43 forwards of 21 this pricing picks — 16, 21 and 24 windows per forward are within 0.6 % of
+        each other, the per-forward overhead decides.)"""
         if count <= 0:
             return []
         cus = max(1, cus)
