@@ -8,7 +8,8 @@ with HIP events on the launch stream (ocm_prof_begin / ocm_prof_end brackets eve
 own algorithmic FLOPs and bytes per forward:
   * window attention (swin_wattn_*): 4 T 49 C FLOPs per layer (scores + context over 7 x 7 windows) and q, k, v in / context out
     = 4 T C E bytes (E = bytes per operand element: 4 for split-bf16 pairs and fp32, 2 for bf16) — byte-bound by two orders of
-    magnitude (24 FLOP per byte), so its roofline is the HBM one;
+    magnitude (24 FLOP per byte), so its roofline is the HBM one; in split-bf16 precision the layers of 96 / 192 channels run
+    their attention half as one kernel (swin_attn_block_x3_kernel) counted in this class with the projections' FLOPs;
   * the GEMM classes: 2 T K N FLOPs against the dense MFMA peak of the mode.
 `kernel_breakdown` lists every class; `profile` names the rocprofv3 summary of the same command committed for this round.
 """
@@ -30,8 +31,11 @@ from vit_ocm_wmsegmentation_amd import synth  # noqa: E402
 PEAK_HBM_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 
 
-def class_work(batch, cfg, esz):
-    """Algorithmic (FLOPs, bytes) per forward of each kernel class of the Swin engine (swin_engine.hip's PROF classes)."""
+def class_work(batch, cfg, esz, fused_attn=False):
+    """Algorithmic (FLOPs, bytes) per forward of each kernel class of the Swin engine (swin_engine.hip's PROF classes).
+    fused_attn (split-bf16 precision, round 4): the layers of 96 channels run layernorm_before, q | k | v, window attention, o_proj
+    and the residual as ONE kernel profiled under `attention` (x read twice, written once), those of 192 channels everything up
+    to the context pairs (x read once, context written); their FLOPs and bytes move to that class."""
     side = cfg["image_size"] // cfg["patch_size"]
     C0, ws, ratio = cfg["embed_dim"], cfg["window_size"], cfg["mlp_ratio"]
     work = {k: [0.0, 0.0] for k in ("patch_embed", "qkv_gemm", "attention", "proj_gemm", "fc1_gemm", "fc2_gemm")}
@@ -42,12 +46,22 @@ def class_work(batch, cfg, esz):
         Cs = C0 << st
         M = int(ratio * Cs)
         for _ in range(depth):
-            work["qkv_gemm"][0] += 2.0 * T * Cs * 3 * Cs
-            work["qkv_gemm"][1] += 4.0 * T * Cs + esz * T * 3 * Cs
-            work["attention"][0] += 4.0 * T * ws * ws * Cs
-            work["attention"][1] += esz * T * 4 * Cs
-            work["proj_gemm"][0] += 2.0 * T * Cs * Cs
-            work["proj_gemm"][1] += esz * T * Cs + 8.0 * T * Cs
+            if fused_attn and Cs in (96, 192):
+                work["attention"][0] += 4.0 * T * ws * ws * Cs + 2.0 * T * Cs * 3 * Cs
+                if Cs == 96:  # the whole half in one kernel
+                    work["attention"][0] += 2.0 * T * Cs * Cs
+                    work["attention"][1] += 12.0 * T * Cs
+                else:  # up to the context pairs; o_proj stays a GEMM
+                    work["attention"][1] += 4.0 * T * Cs + esz * T * Cs
+                    work["proj_gemm"][0] += 2.0 * T * Cs * Cs
+                    work["proj_gemm"][1] += esz * T * Cs + 8.0 * T * Cs
+            else:
+                work["qkv_gemm"][0] += 2.0 * T * Cs * 3 * Cs
+                work["qkv_gemm"][1] += 4.0 * T * Cs + esz * T * 3 * Cs
+                work["attention"][0] += 4.0 * T * ws * ws * Cs
+                work["attention"][1] += esz * T * 4 * Cs
+                work["proj_gemm"][0] += 2.0 * T * Cs * Cs
+                work["proj_gemm"][1] += esz * T * Cs + 8.0 * T * Cs
             work["fc1_gemm"][0] += 2.0 * T * Cs * M
             work["fc1_gemm"][1] += 4.0 * T * Cs + esz * T * M
             work["fc2_gemm"][0] += 2.0 * T * M * Cs
@@ -98,7 +112,7 @@ def main():
     esz = 2 if a.precision == "bf16" else 4
     mpp = 3 if a.precision == "bf16x3" else 1
     peak_mfma = 157.3 if a.precision == "fp32" else 2500.0  # exact-fp32 MFMA / dense bf16 MFMA
-    work = class_work(a.batch, synth.SWIN_TINY, esz)
+    work = class_work(a.batch, synth.SWIN_TINY, esz, fused_attn=a.precision == "bf16x3")
     breakdown = {}
     for i, name in enumerate(_lib.KERNEL_CLASSES):
         if cnt[i]:
