@@ -267,6 +267,35 @@ def test_swin_fused_attention_half_op(lib, dev, B, H, W, ws, shift, heads):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("heads,H", [(3, 56), (6, 28)])
+def test_swin_fused_attention_half_is_deterministic(lib, dev, heads, H):
+    """The fused attention half hands K / V images and weight chunks between wavefronts through LDS behind counted waits and
+    barriers: a misplaced wait shows as run-to-run differences long before it shows against a reference. Sixteen images of
+    the stage's grid (thousands of workgroups in flight), shifted windows, five runs from the same input: identical bits."""
+    from vit_ocm_wmsegmentation_amd.engine import to_operand
+    B, ws, shift, Cn = 16, 7, 3, heads * 32
+    g = torch.Generator().manual_seed(heads)
+    x = (torch.randn(B * H * H, Cn, generator=g) * 1.5).to(dev)
+    gam, bet = (torch.randn(Cn, generator=g) * 0.2 + 1).to(dev), (torch.randn(Cn, generator=g) * 0.1).to(dev)
+    wq = to_operand((torch.randn(3 * Cn, Cn, generator=g) * 0.12).to(dev), _lib.OCM_PREC_BF16X3)
+    wo = to_operand((torch.randn(Cn, Cn, generator=g) * 0.1).to(dev), _lib.OCM_PREC_BF16X3)
+    bq, bo = (torch.randn(3 * Cn, generator=g) * 0.1).to(dev), (torch.randn(Cn, generator=g) * 0.1).to(dev)
+    table = torch.randn((2 * ws - 1) ** 2, heads, generator=g).to(dev)
+    scratch = torch.empty(heads * 4096 + B * H * H * Cn, dtype=torch.float32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for _ in range(5):
+        xg = x.clone()
+        _lib.check(lib.ocm_op_swin_attn_block(_lib.OCM_PREC_BF16X3, p(xg), p(gam), p(bet), p(wq), p(bq), p(wo), p(bo), p(table),
+                                              p(scratch), B, H, H, ws, shift, heads, 1e-5, st))
+        outs.append(xg)
+    assert torch.isfinite(outs[0]).all() and not torch.equal(outs[0], x)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+@pytest.mark.gpu
 def test_swin_fused_mlp_agrees_with_three_launches(lib, dev):
     """OCM_SWIN_OPT_FUSE_MLP on / off (fused MLP and fused LayerNorm + qkv kernels of the narrow stage against LayerNorm kernels
     and GEMMs): the same model, logits and hidden states agree to fp32 rounding."""
