@@ -84,9 +84,9 @@ int ocm_op_swin_mlp(int32_t precision, float *x, const float *gamma, const float
  * bias and the shift mask, SwinSelfOutput, residual) in one kernel: x (batch * height * width, 32 * heads) fp32, in place,
  * x += Wo window_attention(q | k | v of LayerNorm(x; gamma, beta, eps)) + bo. wqkv (3 * C, C) (rows q | k | v) and wo (C, C)
  * as split pairs (ocm_op_cast_split); rel_table: (2*ws-1)^2 x heads fp32 device table; scratch: heads * 4096 floats of device
- * memory, plus batch * height * width * C floats with 6 heads. Built for OCM_PREC_BF16X3 and 3 heads (C = 96, stage 0 of
- * Swin-T: one kernel) or 6 heads (C = 192, stage 1: one kernel up to the context + the o_proj GEMM); anything else returns
- * OCM_EINVAL. */
+ * memory, plus batch * height * width * C floats with 4 or 6 heads. Built for OCM_PREC_BF16X3 and 3 heads (C = 96, stage 0 of
+ * Swin-T: one kernel), 4 heads (C = 128) or 6 heads (C = 192, stage 1 of Swin-T): one kernel up to the context + the o_proj GEMM;
+ * anything else returns OCM_EINVAL. */
 int ocm_op_swin_attn_block(int32_t precision, float *x, const float *gamma, const float *beta, const void *wqkv,
                            const float *bqkv, const void *wo, const float *bo, const float *rel_table, float *scratch,
                            int32_t batch, int32_t height, int32_t width, int32_t window, int32_t shift, int32_t heads, float eps,

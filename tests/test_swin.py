@@ -232,7 +232,7 @@ def _attention_half_oracle(x, gam, bet, wqkv, bqkv, wo, bo, table, B, H, W, head
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,ws,shift,heads", [(2, 14, 14, 7, 0, 3), (2, 14, 14, 7, 3, 3), (3, 7, 7, 7, 0, 3), (1, 12, 8, 4, 2, 3),
                                                   (2, 56, 56, 7, 3, 3), (2, 14, 14, 7, 3, 6), (3, 7, 7, 7, 0, 6), (1, 8, 12, 4, 2, 6),
-                                                  (2, 28, 28, 7, 0, 6)])
+                                                  (2, 28, 28, 7, 0, 6), (2, 14, 14, 7, 3, 4), (3, 12, 8, 4, 0, 4)])
 def test_swin_fused_attention_half_op(lib, dev, B, H, W, ws, shift, heads):
     """ocm_op_swin_attn_block (layernorm_before + q | k | v + (shifted-)window attention + o_proj + residual in one kernel,
     split-bf16; 3 heads: all of it in one kernel, 6 heads: up to the context, then the o_proj GEMM) against float64 torch
@@ -259,7 +259,7 @@ def test_swin_fused_attention_half_op(lib, dev, B, H, W, ws, shift, heads):
     assert torch.isfinite(got).all()
     err = (got - want).abs().max().item()
     print(f"GPUTEST swin fused attention half B={B} {H}x{W} ws{ws} shift{shift} heads{heads}: max|d| = {err:.2e}")
-    assert err <= 1e-4 * heads / 3  # sums over C = 32 * heads terms
+    assert err <= 1.2e-4 * heads / 3  # sums over C = 32 * heads terms
     assert lib.ocm_op_swin_attn_block(_lib.OCM_PREC_BF16, p(xg), p(dv[0]), p(dv[1]), p(wq_s), p(dv[2]), p(wo_s), p(dv[3]), p(dv[4]),
                                       p(scratch), B, H, W, ws, shift, heads, 1e-5, st) == _lib.OCM_EINVAL
     assert lib.ocm_op_swin_attn_block(_lib.OCM_PREC_BF16X3, p(xg), p(dv[0]), p(dv[1]), p(wq_s), p(dv[2]), p(wo_s), p(dv[3]),
@@ -332,3 +332,23 @@ def test_swin_single_channel_batch_one_vs_oracle(dev):
     assert (out.last_hidden_state.cpu() - want["last_hidden_state"]).abs().max().item() <= 1e-3
     with pytest.raises(ValueError):
         model(pixel_values=torch.zeros(1, 3, 56, 56, device=dev))
+
+
+@pytest.mark.gpu
+def test_swin_embed_dim_128_vs_oracle(dev):
+    """embed_dim 128 (the Swin-B family's channel counts: 4 / 8 heads): stage 0 runs the fused attention half up to the context
+    (C = 128) and the fused MLP, stage 1 (C = 256) the unfused chain; split-bf16 and fp32 against the transformers-pinned oracle
+    on the same synthetic weights, with shifted windows in both stages."""
+    cfg = dict(synth.SWIN_TINY, image_size=112, embed_dim=128, depths=(2, 2), num_heads=(4, 8), num_labels=4)
+    sd = synth.synth_swin_state_dict(cfg, seed=41, qk_gain=4.0)
+    x = synth.synth_tiles(2, 112, seed=78)
+    want = SO.swin_forward(sd, cfg, x)
+    hf = SW.SwinConfig(image_size=112, embed_dim=128, depths=cfg["depths"], num_heads=cfg["num_heads"], num_labels=4)
+    model = SW.SwinForImageClassification(hf)
+    assert not model.load_state_dict(sd, strict=True).missing_keys
+    for prec, tol in (("bf16x3", 1e-3), ("fp32", 2e-4)):
+        out = model.to(dev).eval().set_precision(prec)(pixel_values=x.to(dev), output_hidden_states=True)
+        d = (out.logits.cpu() - want["logits"]).abs().max().item()
+        dh = (out.last_hidden_state.cpu() - want["last_hidden_state"]).abs().max().item()
+        print(f"GPUTEST swin embed_dim 128 {prec}: logits {d:.2e}, hidden {dh:.2e}")
+        assert d <= tol and dh <= 5 * tol

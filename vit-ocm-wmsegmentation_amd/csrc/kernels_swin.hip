@@ -1483,7 +1483,7 @@ __global__ __launch_bounds__(NW * 64, 2) void swin_attn_block_x3_kernel(float *_
 
 // proj_fused: the whole half in one kernel (C = 96); otherwise (C = 192) the kernel stops at the context pairs
 bool swin_attn_block_fused_supported(int prec, int C, int heads, int ws) {
-    return prec == 2 && (C == 96 || C == 192) && heads * 32 == C && ws >= 2 && ws * ws <= 64;
+    return prec == 2 && (C == 96 || C == 128 || C == 192) && heads * 32 == C && ws >= 2 && ws * ws <= 64;
 }
 bool swin_attn_block_proj_fused(int C) { return C == 96; }
 
@@ -1522,6 +1522,9 @@ hipError_t launch_swin_attn_block(int prec, float *x, const float *g, const floa
     if (C == 96)
         return ws == 7 ? launch_swin_attn_block_t<3, 7, 4, true>(x, g, be, wqkv, bqkv, wo, bo, bias_perm, ctx, gm, total, eps, s)
                        : launch_swin_attn_block_t<3, 0, 4, true>(x, g, be, wqkv, bqkv, wo, bo, bias_perm, ctx, gm, total, eps, s);
+    if (C == 128)  // embed_dim 128 (the Swin-B family's first stage): up to the context, like C = 192
+        return ws == 7 ? launch_swin_attn_block_t<4, 7, 8, false>(x, g, be, wqkv, bqkv, wo, bo, bias_perm, ctx, gm, total, eps, s)
+                       : launch_swin_attn_block_t<4, 0, 8, false>(x, g, be, wqkv, bqkv, wo, bo, bias_perm, ctx, gm, total, eps, s);
     return ws == 7 ? launch_swin_attn_block_t<6, 7, 8, false>(x, g, be, wqkv, bqkv, wo, bo, bias_perm, ctx, gm, total, eps, s)
                    : launch_swin_attn_block_t<6, 0, 8, false>(x, g, be, wqkv, bqkv, wo, bo, bias_perm, ctx, gm, total, eps, s);
 }

@@ -447,7 +447,7 @@ extern "C" int ocm_op_swin_attn_block(int32_t precision, float *x, const float *
         return fail(OCM_EINVAL, "bad window geometry");
     const int Cn = heads * 32;
     if (!swin_attn_block_fused_supported(pc, Cn, heads, window))
-        return fail(OCM_EINVAL, "the fused attention half is built for split-bf16 operands and 3 or 6 heads of 32 channels "
+        return fail(OCM_EINVAL, "the fused attention half is built for split-bf16 operands and 3, 4 or 6 heads of 32 channels "
                                 "(got precision %d, %d heads)", precision, heads);
     hipStream_t s = (hipStream_t)stream;
     const int64_t T = (int64_t)batch * height * width;
