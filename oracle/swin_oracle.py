@@ -62,6 +62,11 @@ def swin_layer(sd, pre, x, H, W, heads, ws_cfg, shift_cfg, eps):
     shortcut = x
     y = F.layer_norm(x, (C,), sd[pre + "layernorm_before.weight"], sd[pre + "layernorm_before.bias"], eps)
     y = y.view(B, H, W, C)
+    # maybe_pad (SwinLayer): zeros to the right / bottom AFTER layernorm_before, up to multiples of the window
+    pad_r, pad_b = (ws - W % ws) % ws, (ws - H % ws) % ws
+    Hp, Wp = H + pad_b, W + pad_r
+    if pad_r or pad_b:
+        y = F.pad(y, (0, 0, 0, pad_r, 0, pad_b))
     if shift > 0:
         y = torch.roll(y, shifts=(-shift, -shift), dims=(1, 2))
     win = window_partition(y, ws).view(-1, ws * ws, C)
@@ -72,7 +77,7 @@ def swin_layer(sd, pre, x, H, W, heads, ws_cfg, shift_cfg, eps):
     v = F.linear(win, sd[a + "v_proj.weight"], sd[a + "v_proj.bias"]).view(-1, ws * ws, heads, d).transpose(1, 2)
     table = sd[a + "relative_position_bias.relative_position_bias_table"]
     bias = table[relative_position_index(ws).view(-1)].view(ws * ws, ws * ws, -1).permute(2, 0, 1).contiguous().unsqueeze(0)
-    mask = shift_mask(H, W, ws, shift)
+    mask = shift_mask(Hp, Wp, ws, shift)  # get_attn_mask(height_pad, width_pad)
     if mask is not None:
         nW = mask.shape[0]
         m = mask.unsqueeze(1).unsqueeze(0).expand(win.shape[0] // nW, -1, -1, -1, -1).reshape(-1, 1, ws * ws, ws * ws)
@@ -83,9 +88,11 @@ def swin_layer(sd, pre, x, H, W, heads, ws_cfg, shift_cfg, eps):
     p = F.softmax(s, dim=-1, dtype=torch.float32)
     o = torch.matmul(p, v).transpose(1, 2).contiguous().reshape(-1, ws * ws, C)
     o = F.linear(o, sd[a + "o_proj.weight"], sd[a + "o_proj.bias"])
-    o = window_reverse(o.view(-1, ws, ws, C), ws, H, W)
+    o = window_reverse(o.view(-1, ws, ws, C), ws, Hp, Wp)
     if shift > 0:
         o = torch.roll(o, shifts=(shift, shift), dims=(1, 2))
+    if pad_r or pad_b:  # the padded positions' outputs are dropped
+        o = o[:, :H, :W, :].contiguous()
     x = shortcut + o.view(B, H * W, C)
     y = F.layer_norm(x, (C,), sd[pre + "layernorm_after.weight"], sd[pre + "layernorm_after.bias"], eps)
     y = F.linear(y, sd[pre + "mlp.fc1.weight"], sd[pre + "mlp.fc1.bias"])
@@ -95,9 +102,11 @@ def swin_layer(sd, pre, x, H, W, heads, ws_cfg, shift_cfg, eps):
 
 
 def patch_merging(sd, pre, x, H, W):
-    """SwinPatchMerging.forward, modeling_swin.py:309-326 (even H, W)."""
+    """SwinPatchMerging.forward, modeling_swin.py:309-326 (maybe_pad: an odd H or W gets one row / column of zeros)."""
     B, L, C = x.shape
     x = x.view(B, H, W, C)
+    if H % 2 or W % 2:
+        x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
     x = torch.cat([x[:, row::2, col::2, :] for col in range(2) for row in range(2)], dim=-1).view(B, -1, 4 * C)
     x = F.layer_norm(x, (4 * C,), sd[pre + "norm.weight"], sd[pre + "norm.bias"], 1e-5)
     return F.linear(x, sd[pre + "reduction.weight"])

@@ -74,4 +74,7 @@ WRAPPER_CASES = {
 SWIN_CASES = {
     "tiny224": dict(batch=2, seed=21, qk_gain=6.0),
     "small56": dict(batch=3, seed=22, qk_gain=6.0, cfg=dict(image_size=56, depths=(2, 2), num_heads=(3, 6))),
+    # transformers' padding paths: grids 30 -> 15 -> 8 (windows of 7: padded to 35 / 21 / 14; the odd 15 x 15 grid gets a row and
+    # a column of zeros in the patch merging)
+    "pad120": dict(batch=2, seed=23, qk_gain=6.0, cfg=dict(image_size=120, depths=(2, 2, 2), num_heads=(3, 6, 12))),
 }

@@ -22,7 +22,7 @@ def _case(name):
     return c, cfg, sd, x
 
 
-@pytest.mark.parametrize("name", ["small56"])
+@pytest.mark.parametrize("name", ["small56", "pad120"])
 def test_oracle_reproduces_transformers_fixture(name):
     c, cfg, sd, x = _case(name)
     g = load_golden("swin_" + name)
@@ -65,8 +65,10 @@ def test_swin_create_rejects_unbuilt_geometries(lib):
         h = C.c_void_p(0)
         return lib.ocm_swin_create(C.byref(cfg), C.byref(h))
 
-    for bad in (dict(patch_size=8), dict(window_size=8), dict(image_size=200), dict(heads=(4, 6, 12, 24)), dict(embed_dim=100),
-                dict(num_labels=0), dict(precision=3), dict(precision=-1)):
+    # (image_size 96: the third stage's 6 x 6 grid is smaller than the window, which transformers itself cannot run; 202 is not
+    # a multiple of the patch size. Grids that are not multiples of the window, or odd, are padded since round 4: 200 is built)
+    for bad in (dict(patch_size=8), dict(window_size=8), dict(image_size=96), dict(image_size=202), dict(heads=(4, 6, 12, 24)),
+                dict(embed_dim=100), dict(num_labels=0), dict(precision=3), dict(precision=-1)):
         assert create(**bad) == _lib.OCM_EINVAL, bad
 
 

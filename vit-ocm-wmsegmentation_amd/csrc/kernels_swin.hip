@@ -168,13 +168,14 @@ __global__ __launch_bounds__(256) void swin_ln_kernel(const float *__restrict__ 
     int C = dim;
     if (MERGE) {
         C = dim >> 2;
-        const int Ho = Hin >> 1, Wo = Win >> 1;
+        const int Ho = (Hin + 1) >> 1, Wo = (Win + 1) >> 1;  // SwinPatchMerging.maybe_pad: an odd side gets a row / column of zeros
         const size_t b = rr / ((size_t)Ho * Wo);
         const int rem = (int)(rr - b * Ho * Wo), yo = rem / Wo, xo = rem - yo * Wo;
 #pragma unroll
         for (int sgm = 0; sgm < 4; ++sgm) {
             const int r = sgm & 1, c = sgm >> 1;
-            src[sgm] = x + ((b * Hin + 2 * yo + r) * Win + 2 * xo + c) * (size_t)C;
+            const bool inside = 2 * yo + r < Hin && 2 * xo + c < Win;
+            src[sgm] = inside ? x + ((b * Hin + 2 * yo + r) * Win + 2 * xo + c) * (size_t)C : nullptr;
         }
     } else {
         src[0] = x + rr * (size_t)dim;
@@ -185,7 +186,13 @@ __global__ __launch_bounds__(256) void swin_ln_kernel(const float *__restrict__ 
     for (int i = 0; i < V; ++i) {
         const int c = (sub + LPR * i) * 4;
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (c < dim) t = MERGE ? *(const f32x4 *)(src[c / C] + c % C) : *(const f32x4 *)(src[0] + c);
+        if (c < dim) {
+            if (MERGE) {
+                if (src[c / C]) t = *(const f32x4 *)(src[c / C] + c % C);
+            } else {
+                t = *(const f32x4 *)(src[0] + c);
+            }
+        }
         v[i] = t;
         sum += (t[0] + t[1]) + (t[2] + t[3]);
     }
@@ -248,6 +255,57 @@ hipError_t launch_swin_ln(int prec, const float *x, const float *g, const float 
     }
     return merge ? launch_swin_ln_e<bf16, true>(x, g, be, (bf16 *)y, rows, dim, ldy, eps, Hin, Win, s)
                  : launch_swin_ln_e<bf16, false>(x, g, be, (bf16 *)y, rows, dim, ldy, eps, Hin, Win, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// SwinLayer.maybe_pad (modeling_swin.py SwinLayer.forward): a grid that is not a multiple of the window is padded with ZERO rows
+// (after layernorm_before) to the right and at the bottom, the attention half runs on the padded grid and the padded
+// positions' outputs are dropped. Two byte-moving kernels around the unchanged projections and window-attention kernels:
+//   swin_pad_rows_kernel : operand rows (B, H, W, row) -> (B, Hp, Wp, row), zeros at the padded positions;
+//   swin_crop_add_kernel : x (B, H, W, C) += y (B, Hp, Wp, C) at the real positions (the residual of the half).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void swin_pad_rows_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst, int H, int W,
+                                                            int Hp, int Wp, int chunks, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / chunks;
+        const int c = (int)(i - row * chunks);
+        const size_t b = row / ((size_t)Hp * Wp);
+        const int rem = (int)(row - b * Hp * Wp), y = rem / Wp, xx = rem - y * Wp;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (y < H && xx < W) v = src[((b * H + y) * W + xx) * (size_t)chunks + c];
+        dst[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void swin_crop_add_kernel(f32x4 *__restrict__ x, const f32x4 *__restrict__ yp, int H, int W, int Hp,
+                                                            int Wp, int chunks, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / chunks;
+        const int c = (int)(i - row * chunks);
+        const size_t b = row / ((size_t)H * W);
+        const int rem = (int)(row - b * H * W), y = rem / W, xx = rem - y * W;
+        x[i] += yp[((b * Hp + y) * Wp + xx) * (size_t)chunks + c];
+    }
+}
+
+// rows of `row_bytes` bytes (a multiple of 16)
+hipError_t launch_swin_pad_rows(const void *src, void *dst, int batch, int H, int W, int Hp, int Wp, size_t row_bytes,
+                                hipStream_t s) {
+    if (row_bytes % 16 || Hp < H || Wp < W || batch <= 0) return hipErrorInvalidValue;
+    const int chunks = (int)(row_bytes / 16);
+    const size_t total = (size_t)batch * Hp * Wp * chunks;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    swin_pad_rows_kernel<<<dim3(blocks), dim3(256), 0, s>>>((const f32x4 *)src, (f32x4 *)dst, H, W, Hp, Wp, chunks, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_swin_crop_add(float *x, const float *yp, int batch, int H, int W, int Hp, int Wp, int C, hipStream_t s) {
+    if (C % 4 || Hp < H || Wp < W || batch <= 0) return hipErrorInvalidValue;
+    const int chunks = C / 4;
+    const size_t total = (size_t)batch * H * W * chunks;
+    const unsigned blocks = (unsigned)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    swin_crop_add_kernel<<<dim3(blocks), dim3(256), 0, s>>>((f32x4 *)x, (const f32x4 *)yp, H, W, Hp, Wp, chunks, total);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------

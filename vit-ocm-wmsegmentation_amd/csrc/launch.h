@@ -151,6 +151,10 @@ hipError_t launch_swin_embed(const float *img, const float *w, const float *bias
                              float *x, int batch, int chans, int size, int c0, float eps, hipStream_t s);
 hipError_t launch_swin_ln(int prec, const float *x, const float *g, const float *be, void *y, size_t rows, int dim,
                           int ldy, float eps, bool merge, int Hin, int Win, hipStream_t s);
+// SwinLayer.maybe_pad: operand rows to / the attention half's fp32 output from a grid padded to multiples of the window
+hipError_t launch_swin_pad_rows(const void *src, void *dst, int batch, int H, int W, int Hp, int Wp, size_t row_bytes,
+                                hipStream_t s);
+hipError_t launch_swin_crop_add(float *x, const float *yp, int batch, int H, int W, int Hp, int Wp, int C, hipStream_t s);
 hipError_t launch_swin_bias_perm(const float *table, float *perm, float *dense, int heads, int ws, hipStream_t s);
 hipError_t launch_swin_window_attention(int prec, const void *qkv, int ld, void *ctx, int ldc, const float *bias_perm,
                                         const float *bias_dense, int batch, int H, int W, int ws, int shift, int heads,

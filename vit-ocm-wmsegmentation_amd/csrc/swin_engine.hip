@@ -101,13 +101,12 @@ extern "C" int ocm_swin_create(const ocm_swin_config *cfg, ocm_swin_t **out) {
         if (cfg->depths[s] <= 0) return fail(OCM_EINVAL, "depths[%d] must be positive", s);
         if (cfg->num_heads[s] <= 0 || C != cfg->num_heads[s] * 32)
             return fail(OCM_EINVAL, "stage %d: head_dim must be 32 (channels %d, heads %d)", s, C, cfg->num_heads[s]);
-        if (grid < cfg->window_size || grid % cfg->window_size)
-            return fail(OCM_EINVAL, "stage %d grid %d is not a positive multiple of window_size %d (padding path not built)",
-                        s, grid, cfg->window_size);
-        if (s + 1 < cfg->num_stages) {
-            if (grid % 2) return fail(OCM_EINVAL, "stage %d grid %d is odd (padded patch merging not built)", s, grid);
-            grid /= 2;
-        }
+        // a grid that is not a multiple of the window is padded (SwinLayer.maybe_pad), an odd one gets a row / column of zeros in
+        // the patch merging (SwinPatchMerging.maybe_pad); a grid SMALLER than the window is what transformers itself cannot
+        // run (set_shift_and_window_size shrinks the window, the relative-position bias keeps the configured size)
+        if (grid < cfg->window_size)
+            return fail(OCM_EINVAL, "stage %d grid %d is smaller than window_size %d", s, grid, cfg->window_size);
+        if (s + 1 < cfg->num_stages) grid = (grid + 1) / 2;
     }
     const int M4 = (int)(cfg->mlp_ratio * cfg->embed_dim);
     if (M4 <= 0 || M4 % 32) return fail(OCM_EINVAL, "mlp_ratio * embed_dim must be a multiple of 32");
@@ -243,26 +242,52 @@ hipError_t swin_linear(int prec, const void *a, int64_t lda, const void *w, cons
 struct SwinWs {
     float *x, *x2;  // residual stream ping-pong (patch merging writes the other one)
     void *xn, *qkv, *ctx, *hid;
+    void *xnp;   // operand rows on the padded grid (stages whose grid is not a multiple of the window)
+    float *yp;   // the attention half's fp32 output on the padded grid
     size_t bytes;
 };
 
 SwinWs carve_swin(const ocm_swin *h, int batch, char *base) {
-    const int hp = h->cfg.image_size / 4, C0 = h->cfg.embed_dim;
-    const size_t T0 = (size_t)batch * hp * hp;
-    const size_t M0 = (size_t)(h->cfg.mlp_ratio * C0);
+    const int ws = h->cfg.window_size;
     size_t off = 0;
     auto take = [&](size_t bytes) {
         char *p = base ? base + off : nullptr;
         off += (bytes + 255) & ~(size_t)255;
         return p;
     };
+    // per-stage sizes: real tokens T, tokens on the grid padded to the window Tp, merged tokens T4 (ceil: odd grids are padded)
+    size_t x_b = 0, x2_b = 0, xn_b = 0, qkv_b = 0, ctx_b = 0, hid_b = 0, xnp_b = 0, yp_b = 0;
+    int H = h->cfg.image_size / 4;
+    for (int st = 0; st < h->cfg.num_stages; ++st) {
+        const int C = h->chans(st), M = (int)(h->cfg.mlp_ratio * C), Kc = h->Kp(C), Km = h->Kp(M);
+        const int Hp = round_up(H, ws);
+        const size_t T = (size_t)batch * H * H, Tp = (size_t)batch * Hp * Hp;
+        const bool pad = Hp != H;
+        auto up = [](size_t &a, size_t b) { a = b > a ? b : a; };
+        up(st % 2 ? x2_b : x_b, T * C * 4);
+        up(xn_b, T * Kc * h->esz);
+        up(qkv_b, (pad ? Tp : T) * 3 * C * h->esz);
+        up(ctx_b, (pad ? Tp : T) * Kc * h->esz);
+        up(hid_b, T * Km * h->esz);
+        if (pad) {
+            up(xnp_b, Tp * Kc * h->esz);
+            up(yp_b, Tp * C * 4);
+        }
+        if (st + 1 < h->cfg.num_stages) {
+            const int Hn = (H + 1) / 2;
+            up(xn_b, (size_t)batch * Hn * Hn * h->Kp(4 * C) * h->esz);  // patch merging: LayerNorm(4C) rows
+            H = Hn;
+        }
+    }
     SwinWs w;
-    w.x = (float *)take(T0 * C0 * 4);
-    w.x2 = (float *)take(T0 * C0 * 2);  // T0/4 tokens x 2*C0 channels
-    w.xn = take(T0 * (size_t)h->Kp(C0) * h->esz);
-    w.qkv = take(T0 * 3 * C0 * h->esz);
-    w.ctx = take(T0 * (size_t)h->Kp(C0) * h->esz);
-    w.hid = take(T0 * (size_t)h->Kp((int)M0) * h->esz);
+    w.x = (float *)take(x_b);
+    w.x2 = (float *)take(x2_b);
+    w.xn = take(xn_b);
+    w.qkv = take(qkv_b);
+    w.ctx = take(ctx_b);
+    w.hid = take(hid_b);
+    w.xnp = take(xnp_b);
+    w.yp = (float *)take(yp_b);
     w.bytes = off;
     return w;
 }
@@ -304,6 +329,35 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
         for (size_t b = 0; b < h->stages[st].layers.size(); ++b) {
             const LayerP &lp = h->stages[st].layers[b];
             const int shift = (b % 2 == 1 && H > ws) ? ws / 2 : 0;  // set_shift_and_window_size :576-582
+            const int Hp = round_up(H, ws);
+            if (Hp != H) {
+                // maybe_pad: LayerNorm rows -> the padded grid (zeros at the padded positions), projections and window attention on
+                // Hp x Hp tokens, the half's output added back at the real positions (unfused chain, any precision)
+                const size_t Tp = (size_t)batch * Hp * Hp;
+                if (Tp > 0x7fffffff) return fail(OCM_EINVAL, "too many tokens");
+                {
+                    PROF(OCM_K_LN, s);
+                    HIP_TRY(launch_swin_ln(pc, x, h->ptr<float>(lp.ln1_g), h->ptr<float>(lp.ln1_b), w.xn, T, C, Kc, eps, false, 0, 0, s));
+                    HIP_TRY(launch_swin_pad_rows(w.xn, w.xnp, batch, H, H, Hp, Hp, (size_t)Kc * h->esz, s));
+                }
+                {
+                    PROF(OCM_K_QKV, s);
+                    HIP_TRY(swin_linear(pc, w.xnp, Kc, h->ptr<char>(lp.wqkv), h->ptr<float>(lp.bqkv), nullptr, w.qkv, 3 * C, (int)Tp,
+                                             3 * C, Kc, OCM_EPI_BIAS_BF16, s));
+                }
+                {
+                    PROF(OCM_K_ATTN, s);
+                    if (Kc != C) HIP_TRY(hipMemsetAsync(w.ctx, 0, Tp * Kc * h->esz, s));
+                    HIP_TRY(launch_swin_window_attention(pc, w.qkv, 3 * C, w.ctx, Kc, h->ptr<float>(lp.bias_perm),
+                                                         h->ptr<float>(lp.bias_dense), batch, Hp, Hp, ws, shift, heads, s));
+                }
+                {
+                    PROF(OCM_K_PROJ, s);
+                    HIP_TRY(swin_linear(pc, w.ctx, Kc, h->ptr<char>(lp.wo), h->ptr<float>(lp.bo), nullptr, w.yp, C, (int)Tp, C, Kc,
+                                             OCM_EPI_BIAS_F32, s));
+                    HIP_TRY(launch_swin_crop_add(x, w.yp, batch, H, H, Hp, Hp, C, s));
+                }
+            } else
             // kernel classes for ocm_prof_begin / ocm_prof_end (tools/bench_swin.py): LayerNorm kernels -> layernorm; the q|k|v
             // projection (fused with layernorm_before or not) -> qkv_gemm; window attention -> attention; attention.output.dense
             // and the patch-merging reduction -> proj_gemm; mlp.fc1 (and the fused LayerNorm + MLP kernel) -> fc1_gemm; mlp.fc2 -> fc2_gemm
@@ -374,7 +428,8 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
         }
         if (st + 1 < c.num_stages) {  // SwinPatchMerging :309-326
             const StageP &sp = h->stages[st];
-            const size_t T4 = T / 4;
+            const int Hn = (H + 1) / 2;  // SwinPatchMerging.maybe_pad: odd grids gain a row / column of zeros
+            const size_t T4 = (size_t)batch * Hn * Hn;
             const int K4 = h->Kp(4 * C);
             {
                 PROF(OCM_K_LN, s);
@@ -389,7 +444,7 @@ extern "C" int ocm_swin_forward(ocm_swin_t *h, const float *pixel_values, int32_
             float *t = x;
             x = xo;
             xo = t;
-            H /= 2;
+            H = Hn;
         }
     }
     const int Cl = h->chans(c.num_stages - 1);

@@ -134,7 +134,10 @@ class SwinForImageClassification(nn.Module):
         x = pixel_values.detach().to(torch.float32).contiguous()
         dev, B = x.device, x.shape[0]
         eng, lib = self._get_engine(dev), _lib.load()
-        L = (c.image_size // c.patch_size // 2 ** (c.num_layers - 1)) ** 2
+        side = c.image_size // c.patch_size
+        for _ in range(c.num_layers - 1):  # SwinPatchMerging.maybe_pad: an odd grid is padded to an even one before it is halved
+            side = (side + 1) // 2
+        L = side * side
         logits = torch.empty((B, c.num_labels), dtype=torch.float32, device=dev)
         pooled = torch.empty((B, c.hidden_size), dtype=torch.float32, device=dev)
         hidden = torch.empty((B, L, c.hidden_size), dtype=torch.float32, device=dev) if output_hidden_states else None
