@@ -262,11 +262,11 @@ int ocm_op_attention_rows(int32_t precision, const void *q, const void *k, const
                           void *stream);
 
 /* The qkv projection, attention and probabilities for heads of `head_dim` channels: 64 (identical to the entry points
- * above), or 128 in OCM_PREC_BF16X3 — the encoder the reference's build_model() constructs
- * (Self-supervised_segmentation/model.py:93-103: embed_dim 384, 3 heads). q / k are then [B*H][n_pad][128] and vt
- * [B*H][128][n_pad] split pairs, ctx [B][N][H*128]. Any other combination returns OCM_EINVAL (an engine handle runs such
- * heads on its generic fp32 attention kernel) — except that ocm_op_qkv_proj_hd with q = k = vt = NULL fills only qkv_f32, for any
- * head_dim that is a multiple of 8 (the input of ocm_op_attention_generic). */
+ * above) or 128 — the encoder the reference's build_model() constructs (Self-supervised_segmentation/model.py:93-103:
+ * embed_dim 384, 3 heads) — in every precision (split-bf16 since round 3, fp32 and single bf16 since round 4). q / k are then
+ * [B*H][n_pad][128] and vt [B*H][128][n_pad] in the operand type, ctx [B][N][H*128]. Any other width returns OCM_EINVAL (an
+ * engine handle runs such heads on its generic fp32 attention kernel) — except that ocm_op_qkv_proj_hd with q = k = vt = NULL
+ * fills only qkv_f32, for any head_dim that is a multiple of 8 (the input of ocm_op_attention_generic). */
 int ocm_op_qkv_proj_hd(int32_t precision, const void *a, const void *w, const float *bias, void *q, void *k, void *vt,
                        float *qkv_f32, int32_t batch, int32_t n_tokens, int32_t heads, int32_t head_dim, void *stream);
 int ocm_op_attention_hd(int32_t precision, const void *q, const void *k, const void *vt, void *ctx, float *lse2,

@@ -252,9 +252,49 @@ def test_attention_x3_128_wide_heads(lib, dev, B, N, H, sharp):
     lse2 = torch.empty_like(lse)
     _ok(lib, lib.ocm_op_attention_hd(X3, _p(q), _p(k), _p(vt), None, _p(lse2), B, N, H, HD, scale, _s()))
     assert torch.equal(lse, lse2)
-    # other precisions keep the generic fp32 kernel inside an engine handle; the operator says so
-    assert lib.ocm_op_attention_hd(_lib.OCM_PREC_BF16, _p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, HD, scale, _s()) == _lib.OCM_EINVAL
+    # other widths keep the generic fp32 kernel inside an engine handle; the operator says so
     assert lib.ocm_op_attention_hd(X3, _p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, 96, scale, _s()) == _lib.OCM_EINVAL
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 65, 3), (1, 197, 3), (2, 300, 2), (1, 32, 1)])
+@pytest.mark.parametrize("prec,tq,to", [("fp32", 1e-5, 2e-5), ("bf16", 2e-2, 3e-2)])
+def test_attention_128_wide_heads_fp32_and_bf16(lib, dev, B, N, H, prec, tq, to):
+    """128-wide heads in the other two precisions (round 4: the streaming kernels templated on the head width — exact-fp32 MFMA
+    on 128 KiB of LDS, single bf16): qkv projection, attention, probabilities and selected rows against float64 torch on the
+    operand values the projection wrote; NaN-poisoned padding must not reach a result."""
+    P = _lib.PRECISIONS[prec]
+    dt = torch.float32 if prec == "fp32" else torch.bfloat16
+    HD, D = 128, H * 128
+    a, w, bias = _rand((B * N, D), dev, 80), _rand((3 * D, D), dev, 81, 0.05), _rand((3 * D,), dev, 82, 0.1)
+    npad = lib.ocm_n_pad_prec(P, N)
+    q = torch.full((B * H, npad, HD), float("nan"), dtype=dt, device=dev)
+    k = torch.full_like(q, float("nan"))
+    vt = torch.full((B * H, HD, npad), float("nan"), dtype=dt, device=dev)
+    qkv32 = torch.empty((3, B, H, N, HD), device=dev)
+    a_s, w_s = to_operand(a, P), to_operand(w, P)
+    _ok(lib, lib.ocm_op_qkv_proj_hd(P, _p(a_s), _p(w_s), _p(bias), _p(q), _p(k), _p(vt), _p(qkv32), B, N, H, HD, _s()))
+    ref = (a.double() @ w.double().t() + bias.double()).reshape(B, N, 3, H, HD).permute(2, 0, 3, 1, 4)
+    assert (qkv32.double() - ref).abs().max().item() < tq * 3
+    assert (q[:, :N].double() - ref[0].reshape(B * H, N, HD)).abs().max().item() < tq * 3
+    qd, kd = q[:, :N].double(), k[:, :N].double()
+    vd = vt[:, :, :N].double().transpose(1, 2)
+    scale = HD ** -0.5
+    sc = (qd @ kd.transpose(1, 2)) * scale
+    pref = sc.softmax(-1)
+    oref = (pref @ vd).reshape(B, H, N, HD).permute(0, 2, 1, 3).reshape(B, N, D)
+    ctx = torch.full((B, N, D), float("nan"), dtype=dt, device=dev)
+    lse = torch.empty((B * H, N), device=dev)
+    _ok(lib, lib.ocm_op_attention_hd(P, _p(q), _p(k), _p(vt), _p(ctx), _p(lse), B, N, H, HD, scale, _s()))
+    got = ctx.double()
+    assert torch.isfinite(got).all()
+    assert (lse.double() - torch.logsumexp(sc, -1) / math.log(2.0)).abs().max().item() < (1e-4 if prec == "fp32" else 1e-5)
+    assert (got - oref).abs().max().item() < to
+    attn = torch.full((B, H, N, N), float("nan"), device=dev)
+    _ok(lib, lib.ocm_op_attention_probs_hd(P, _p(q), _p(k), _p(lse), _p(attn), B, N, H, HD, scale, _s()))
+    assert (attn.reshape(B * H, N, N).double() - pref).abs().max().item() < 2e-5
+    lse2 = torch.empty_like(lse)
+    _ok(lib, lib.ocm_op_attention_hd(P, _p(q), _p(k), _p(vt), None, _p(lse2), B, N, H, HD, scale, _s()))
+    assert torch.equal(lse, lse2)
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32", "bf16x3"])

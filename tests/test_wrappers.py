@@ -39,16 +39,19 @@ def test_oracle_reproduces_reference_wrappers(name):
     p, S = c["patch"], c["img_size"]
     wp1 = synth.synth_wrapper_params(c["dim"], p, 1, seed=c["seed"])
     wp3 = synth.synth_wrapper_params(c["dim"], p, 3, seed=c["seed"])
+    # (the fixtures are the reference's outputs on the build container's CPU, where the oracle reproduces them exactly —
+    # `oracle_vs_reference_maxabs` above; torch's fp32 CPU GEMMs sum in another order on another CPU model: a few 1e-6 on O(1) maps)
+    tol = 1e-5
     z = O.encoder_fmap(sd, cfg, x, S)
-    assert np.abs(z.numpy() - g[name + "_fmap"]).max() <= 1e-6
+    assert np.abs(z.numpy() - g[name + "_fmap"]).max() <= tol
     rec2 = O.two_layer_decoder(z, synth.synth_two_layer_decoder_params(c["dim"], p, seed=c["seed"]), p)
-    assert np.abs(rec2.numpy() - g[name + "_rec2"]).max() <= 1e-6
+    assert np.abs(rec2.numpy() - g[name + "_rec2"]).max() <= tol
     rec1 = O.conv1x1_pixel_shuffle(z, wp1["decoder.weight"], wp1["decoder.bias"], p)
-    assert np.abs(rec1.numpy() - g[name + "_rec1"]).max() <= 1e-6
+    assert np.abs(rec1.numpy() - g[name + "_rec1"]).max() <= tol
     loss, rec3, _ = O.mim_forward(sd, cfg, x, mask, S, wp3["mask_token"], wp3["decoder.weight"], wp3["decoder.bias"], p,
                                   patch_size=p)
-    assert np.abs(rec3.numpy() - g[name + "_rec3"]).max() <= 1e-6
-    assert abs(float(loss) - float(g[name + "_loss"])) <= 1e-6
+    assert np.abs(rec3.numpy() - g[name + "_rec3"]).max() <= tol
+    assert abs(float(loss) - float(g[name + "_loss"])) <= tol
 
 
 def test_wrapper_surface_and_state_dict_keys():
@@ -121,7 +124,10 @@ def test_wrappers_match_reference_fixtures(dev, name, precision, tol):
     assert not enc.load_state_dict(dict(sd, mask_token=wp3["mask_token"]), strict=True).missing_keys
     enc = enc.to(dev).eval().set_precision(precision)
     zm = enc(x.to(dev), mask.to(dev))
-    assert np.abs(zm.cpu().numpy() - g[name + "_fmap_masked"]).max() <= tol
+    # (128-wide heads in single-bf16 precision run the bf16 MFMA attention since round 4 — fp32 FMAs before: a 128-term score of
+    # 8-bit operands and probabilities rounded to bf16 show in the masked map, 3.5e-2 on this fixture)
+    tol_m = 5e-2 if (precision == "bf16" and c["dim"] // c["heads"] == 128) else tol
+    assert np.abs(zm.cpu().numpy() - g[name + "_fmap_masked"]).max() <= tol_m
     mim = M.MIM(enc, p).to(dev).eval()
     mim.patch_size = p
     mim.decoder[0].weight.data.copy_(wp3["decoder.weight"])
@@ -171,7 +177,7 @@ def test_reference_build_model_runs_with_128_channel_heads(dev):
     x = synth.synth_tiles(2, 64, seed=c["seed"] + 100)
     mask = synth.synth_patch_mask(2, 8, seed=c["seed"])
     g = load_golden("wrappers")
-    for precision, tol in (("bf16x3", 2e-4), ("fp32", 2e-5), ("bf16", 3e-2)):
+    for precision, tol in (("bf16x3", 2e-4), ("fp32", 2e-5), ("bf16", 5e-2)):  # (bf16: the bf16 MFMA attention since round 4)
         z = enc.set_precision(precision)(x.to(dev), mask.to(dev))
         assert np.abs(z.cpu().numpy() - g["wrap_mim_hd128_fmap_masked"]).max() <= tol
     # per-head attention maps of 128-channel heads against the oracle
@@ -187,6 +193,12 @@ def test_reference_build_model_runs_with_128_channel_heads(dev):
     # 128-wide heads run the split-bf16 MFMA attention kernels like 64-wide ones: the selected rows come from their own
     # fp32 dot-product kernel (never the (H,N,N) matrix), so they match the matrix to rounding, as in test_model_gpu.py
     assert float((rows - attns[0][:, :, [0, 7], 1:]).abs().max()) < 2e-5
-    # the fp32 and bf16 modes keep the generic fp32 attention for such heads; the attention maps agree across modes
+    # the fp32 and bf16 modes run their own MFMA kernels templated on the head width since round 4 (exact-fp32 / single bf16);
+    # the attention maps agree with the oracle in their mode's tolerance, and both entry points return the same bits
     a32 = enc.set_precision("fp32").get_last_selfattention(x.to(dev))
     assert float((a32.cpu() - oattn[0]).abs().max()) <= 1e-5
+    assert torch.equal(enc.get_intermediate_feat(x.to(dev), n=1)[1][0], a32)
+    a16 = enc.set_precision("bf16").get_last_selfattention(x.to(dev))
+    assert float((a16.cpu() - oattn[0]).abs().max()) <= 1e-3
+    r16 = enc.get_last_attention_rows(x.to(dev), torch.tensor([0, 7], dtype=torch.int32, device=dev))
+    assert float((r16 - a16[:, :, [0, 7], 1:]).abs().max()) < 2e-5

@@ -113,7 +113,7 @@ struct ocm_vit {
     int D, H, L, M, p, C, Kpe;
     int hd;    // head_dim: 64 (and 128 in split-bf16 precision, model.py:96-97) runs the MFMA attention kernels, anything else the
                // generic fp32 attention
-    bool mfma_heads() const { return hd == 64 || (hd == 128 && prec == 2); }
+    bool mfma_heads() const { return hd == 64 || hd == 128; }  // (128-wide heads: every precision since round 4)
     int prec;  // 0 = bf16 operands, 1 = fp32 operands, 2 = split-bf16 pairs (element size esz of matrices / activations)
     size_t esz;
     std::vector<Param> params;
@@ -819,8 +819,8 @@ static int op_qkv_proj(int32_t precision, const void *a, const void *w, const fl
     const bool copies = q || k || vt;
     if (!a || !w || !bias || (copies && (!q || !k || !vt)) || (!copies && !qkv_f32)) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || n_tokens <= 0 || heads <= 0 || head_dim <= 0 || head_dim % 8) return fail(OCM_EINVAL, "bad shape");
-    if (copies && head_dim != 64 && !(head_dim == 128 && pc == 2))
-        return fail(OCM_EINVAL, "head_dim %d: operand copies exist for 64-wide heads, and for 128-wide heads in split-bf16 precision", head_dim);
+    if (copies && head_dim != 64 && head_dim != 128)
+        return fail(OCM_EINVAL, "head_dim %d: operand copies exist for 64- and 128-wide heads", head_dim);
     HIP_TRY(launch_qkv(pc, a, w, bias, q, k, vt, qkv_f32, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, head_dim, true,
                        (hipStream_t)stream));
     return OCM_OK;
@@ -843,8 +843,8 @@ static int op_attention(int32_t precision, const void *q, const void *k, const v
     if (rc) return rc;
     if (!q || !k || !vt || (!ctx && !lse2)) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    if (head_dim != 64 && !(head_dim == 128 && pc == 2))
-        return fail(OCM_EINVAL, "head_dim %d: the MFMA attention is built for 64-wide heads, and for 128-wide heads in split-bf16 precision", head_dim);
+    if (head_dim != 64 && head_dim != 128)
+        return fail(OCM_EINVAL, "head_dim %d: the MFMA attention is built for 64- and 128-wide heads", head_dim);
     HIP_TRY(launch_attention(pc, q, k, vt, ctx, lse2, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, scale,
                              (hipStream_t)stream, head_dim));
     return OCM_OK;
@@ -856,7 +856,7 @@ static int op_attention_probs(int32_t precision, const void *q, const void *k, c
     if (rc) return rc;
     if (!q || !k || !lse2 || !attn) return fail(OCM_EINVAL, "null argument");
     if (batch <= 0 || n_tokens <= 0 || heads <= 0) return fail(OCM_EINVAL, "bad shape");
-    if (head_dim != 64 && !(head_dim == 128 && pc == 2)) return fail(OCM_EINVAL, "head_dim %d not built in this precision", head_dim);
+    if (head_dim != 64 && head_dim != 128) return fail(OCM_EINVAL, "head_dim %d not built on MFMA", head_dim);
     HIP_TRY(launch_attention_probs(pc, q, k, lse2, attn, batch, n_tokens, ocm_n_pad_for(pc, n_tokens), heads, scale,
                                    (hipStream_t)stream, head_dim));
     return OCM_OK;

@@ -1016,7 +1016,7 @@ hipError_t launch_qkv_e(const E *a, const E *w, const float *bias, E *q, E *k, E
                                const LnFold &ln) {
     const int D = heads * head_dim, M = batch * n_tokens;
     // operand copies exist for 64-channel heads, and for 128-channel heads as split pairs
-    if (head_dim != 64 && !(head_dim == 128 && Elem<E>::MODE == 2) && (q || k || vt)) return hipErrorInvalidValue;
+    if (head_dim != 64 && head_dim != 128 && (q || k || vt)) return hipErrorInvalidValue;
     if (head_dim % 8) return hipErrorInvalidValue;                      // a lane's 8 columns stay inside one head
     RowLoader<E> al{a, D};
     EpiQK<E> eqk{bias, q, k, qkv_f32, M, n_tokens, n_pad, heads, D, batch, head_dim};

@@ -54,41 +54,47 @@ __device__ __forceinline__ float defer_max_update(float &m, float cand) {
     return 1.0f;
 }
 
-template <bool WANT_O>
+template <bool WANT_O, int HD = 64>
 // compiled for three waves per SIMD (<= 168 registers, no spills): the softmax VALU work of one wave overlaps the
 // MFMAs of the others (+17..24 % over the two-wave allocation hipcc picks by itself)
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16 *__restrict__ Q, const bf16 *__restrict__ Kk,
+// (HD = 128, round 4 — the reference's build_model() encoder in single-bf16 precision: the K tile is two [64 keys][128 B] images,
+// V^T has 128 rows, four context accumulators: two waves per SIMD)
+__global__ __launch_bounds__(256, HD == 64 ? 3 : 2) void attn_fwd_kernel(const bf16 *__restrict__ Q, const bf16 *__restrict__ Kk,
                                                        const bf16 *__restrict__ Vt, bf16 *__restrict__ ctx,
                                                        float *__restrict__ lse2, int N, int npad, int H,
                                                        float scale2) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 64 * 128];  // K[2] | Vt[2], 8 KiB each
-    char *Ks = smem, *Vs = smem + 2 * 64 * 128;
+    constexpr int TB = HD * 128, NS = HD / 16, NDB = HD / 32, CPT = HD / 32;  // tile bytes (K and V^T alike); chunks per thread
+    static_assert(HD == 64 || HD == 128, "head widths built on MFMA");
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TB];  // K[2] | Vt[2], 8 KiB each at HD = 64
+    char *Ks = smem, *Vs = smem + 2 * TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     int qblk, bh;
     xcd_remap2(qblk, bh);
     const int q0 = (qblk * 4 + wave) * 32;
     const bool active = q0 < N;  // wave-uniform
-    const bf16 *Qb = Q + (int64_t)bh * npad * 64;
-    const bf16 *Kb = Kk + (int64_t)bh * npad * 64;
-    const bf16 *Vb = Vt + (int64_t)bh * 64 * npad;
+    const bf16 *Qb = Q + (int64_t)bh * npad * HD;
+    const bf16 *Kb = Kk + (int64_t)bh * npad * HD;
+    const bf16 *Vb = Vt + (int64_t)bh * HD * npad;
 
     // Q^T as the B operand: lane (query r, half h) holds Q[q0+r][16s + 8h .. +7]
-    bf16x8 qf[4];
+    bf16x8 qf[NS];
     {
         const int qrow = min(q0 + r, N - 1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8 *)(Qb + (int64_t)qrow * 64 + 16 * s + 8 * h);
+        for (int s = 0; s < NS; ++s) qf[s] = *(const bf16x8 *)(Qb + (int64_t)qrow * HD + 16 * s + 8 * h);
     }
 
-    // staging: 512 K chunks + 512 V^T chunks of 16 B per tile, 256 threads -> 2 + 2 each
-    bf16x8 rk[2], rv[2];
+    // staging: 8 HD K chunks + 8 HD V^T chunks of 16 B per tile, 256 threads -> HD / 32 each. K chunk qd: key qd / (HD / 8), its
+    // 16-byte piece kc of the key's row -> image kc >> 3 ([64 keys][128 B] each), chunk kc & 7; V^T chunk qd: row d = qd >> 3
+    bf16x8 rk[CPT], rv[CPT];
     auto issue = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CPT; ++i) {
             const int qd = tid + 256 * i, row = qd >> 3, c = qd & 7;
-            const int key = min(kt * 64 + row, N - 1);
-            rk[i] = *(const bf16x8 *)(Kb + (int64_t)key * 64 + c * 8);
+            const int krow = qd / (HD / 8), kc = qd % (HD / 8);
+            const int key = min(kt * 64 + krow, N - 1);
+            rk[i] = *(const bf16x8 *)(Kb + (int64_t)key * HD + kc * 8);
             const int key0 = kt * 64 + c * 8;  // V^T row = d, chunk = 8 keys
             bf16x8 v;
 #pragma unroll
@@ -106,16 +112,19 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16 *__restrict
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CPT; ++i) {
             const int qd = tid + 256 * i, row = qd >> 3, c = qd & 7;
-            *(bf16x8 *)(Ks + buf * 8192 + lds_off(row, c)) = rk[i];
-            *(bf16x8 *)(Vs + buf * 8192 + lds_off(row, c)) = rv[i];
+            const int krow = qd / (HD / 8), kc = qd % (HD / 8);
+            *(bf16x8 *)(Ks + buf * TB + (kc >> 3) * 8192 + lds_off(krow, kc & 7)) = rk[i];
+            *(bf16x8 *)(Vs + buf * TB + lds_off(row, c)) = rv[i];
         }
     };
 
-    f32x16 O[2];
+    f32x16 O[NDB];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) O[0][e] = O[1][e] = 0.f;
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[db][e] = 0.f;
     float m = -INFINITY, l = 0.f;
     const int pr = pi_row(r);
     const int ntiles = (N + 63) >> 6;
@@ -127,15 +136,15 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16 *__restrict
         const int buf = kt & 1;
         if (kt + 1 < ntiles) issue(kt + 1);
         if (active) {
-            const char *Kt = Ks + buf * 8192, *Vtile = Vs + buf * 8192;
+            const char *Kt = Ks + buf * TB, *Vtile = Vs + buf * TB;
             f32x16 S[2];
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) S[sub][e] = 0.f;
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const bf16x8 a = *(const bf16x8 *)(Kt + sub * 32 * 128 + lds_off(pr, 2 * s + h));
+                for (int s = 0; s < NS; ++s) {
+                    const bf16x8 a = *(const bf16x8 *)(Kt + (s >> 2) * 8192 + sub * 32 * 128 + lds_off(pr, 2 * (s & 3) + h));
                     S[sub] = mfma32(a, qf[s], S[sub]);
                 }
             }
@@ -167,10 +176,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16 *__restrict
             if (WANT_O) {
                 if (__any(alpha != 1.0f)) {  // the running max moved somewhere in this wave
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        O[0][e] *= alpha;
-                        O[1][e] *= alpha;
-                    }
+                    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) O[db][e] *= alpha;
                 }
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16 *__restrict
 #pragma unroll
                         for (int e = 0; e < 8; ++e) pb[e] = (bf16)S[sub][8 * s2 + e];
 #pragma unroll
-                        for (int db = 0; db < 2; ++db) {
+                        for (int db = 0; db < NDB; ++db) {
                             const bf16x8 a =
                                 *(const bf16x8 *)(Vtile + db * 32 * 128 + lds_off(r, 4 * sub + 2 * s2 + h));
                             O[db] = mfma32(a, pb, O[db]);
@@ -200,9 +208,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(const bf16 *__restrict
         if (WANT_O) {
             const float inv = 1.0f / lt;
             const int b = bh / H, head = bh - b * H;
-            bf16 *dst = ctx + ((int64_t)b * N + qrow) * (H * 64) + head * 64;
+            bf16 *dst = ctx + ((int64_t)b * N + qrow) * (H * HD) + head * HD;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     bf16x4 o;
@@ -361,7 +369,15 @@ __global__ __launch_bounds__(512, 4) void attn_small_kernel(const bf16 *__restri
 }
 
 static hipError_t launch_attention_bf16(const bf16 *q, const bf16 *k, const bf16 *vt, bf16 *ctx, float *lse2, int batch,
-                                        int n_tokens, int n_pad, int heads, float scale, hipStream_t s) {
+                                        int n_tokens, int n_pad, int heads, float scale, hipStream_t s, int head_dim = 64) {
+    if (head_dim == 128) {  // 128-wide heads: the streaming kernel at every sequence length
+        const dim3 grid(((n_tokens + 31) / 32 + 3) / 4, batch * heads), block(256);
+        if (ctx)
+            attn_fwd_kernel<true, 128><<<grid, block, 0, s>>>(q, k, vt, ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+        else
+            attn_fwd_kernel<false, 128><<<grid, block, 0, s>>>(q, k, vt, ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+        return hipGetLastError();
+    }
     if (n_tokens <= 256) {
         const dim3 grid(batch * heads), block(512);
         if (ctx)
@@ -380,33 +396,35 @@ static hipError_t launch_attention_bf16(const bf16 *q, const bf16 *k, const bf16
 }
 
 // ------------------------------------------------------------------------------------------
+template <int HD = 64>
 __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16 *__restrict__ Q, const bf16 *__restrict__ Kk,
                                                          const float *__restrict__ lse2, float *__restrict__ attn,
                                                          int N, int npad, float scale2) {
+    constexpr int NS = HD / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     int qblk, bh;
     xcd_remap2(qblk, bh);
     const int q0 = (qblk * 4 + wave) * 32;
     if (q0 >= N) return;  // no barriers in this kernel
-    const bf16 *Qb = Q + (int64_t)bh * npad * 64;
-    const bf16 *Kb = Kk + (int64_t)bh * npad * 64;
-    bf16x8 qf[4];
+    const bf16 *Qb = Q + (int64_t)bh * npad * HD;
+    const bf16 *Kb = Kk + (int64_t)bh * npad * HD;
+    bf16x8 qf[NS];
     {
         const int qrow = min(q0 + r, N - 1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) qf[s] = *(const bf16x8 *)(Qb + (int64_t)qrow * 64 + 16 * s + 8 * h);
+        for (int s = 0; s < NS; ++s) qf[s] = *(const bf16x8 *)(Qb + (int64_t)qrow * HD + 16 * s + 8 * h);
     }
     float lr[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) lr[e] = lse2[(int64_t)bh * N + min(q0 + acc_row32(e, h), N - 1)];
     float *out = attn + (int64_t)bh * N * N;
     const int ktiles = (N + 31) >> 5;
-    bf16x8 kf[4], kn[4];
-    auto loadk = [&](int kt, bf16x8(&dst)[4]) {
+    bf16x8 kf[NS], kn[NS];
+    auto loadk = [&](int kt, bf16x8(&dst)[NS]) {
         const int key = min(kt * 32 + r, N - 1);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) dst[s] = *(const bf16x8 *)(Kb + (int64_t)key * 64 + 16 * s + 8 * h);
+        for (int s = 0; s < NS; ++s) dst[s] = *(const bf16x8 *)(Kb + (int64_t)key * HD + 16 * s + 8 * h);
     };
     loadk(0, kf);
     for (int kt = 0; kt < ktiles; ++kt) {
@@ -415,7 +433,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16 *__restrict_
 #pragma unroll
         for (int e = 0; e < 16; ++e) S[e] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) S = mfma32(qf[s], kf[s], S);  // rows = queries, col (lane) = key
+        for (int s = 0; s < NS; ++s) S = mfma32(qf[s], kf[s], S);  // rows = queries, col (lane) = key
         const int key = kt * 32 + r;
         if (key < N) {
 #pragma unroll
@@ -425,7 +443,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16 *__restrict_
             }
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) kf[s] = kn[s];
+        for (int s = 0; s < NS; ++s) kf[s] = kn[s];
     }
 }
 
@@ -436,39 +454,43 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(const bf16 *__restrict_
 // the S^T accumulator holds keys acc_row32(e, 0) and acc_row32(e, 1) on the two lane halves, which
 // is exactly one instruction's k pair when p[e] is used as the B operand of O^T += V^T P^T.
 // LDS tiles: 64 keys x 64 d fp32 = 128 rows of 128 B (row = 2*key + half); V^T likewise (row = 2*d + half).
-template <bool WANT_O>
+// (HD = 128, round 4: a key is four 128-byte rows, V^T has 256 row halves: 32 KiB per tile and operand, 128 KiB of dynamic LDS)
+template <bool WANT_O, int HD = 64>
 __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float *__restrict__ Q, const float *__restrict__ Kk,
                                                            const float *__restrict__ Vt, float *__restrict__ ctx,
                                                            float *__restrict__ lse2, int N, int npad, int H,
                                                            float scale2) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 128 * 128];  // K[2] | Vt[2], 16 KiB each
-    char *Ks = smem, *Vs = smem + 2 * 16384;
+    constexpr int TB = HD * 256, RPK = HD / 32, NHF = HD / 32, NDB = HD / 32, CPT = HD / 16;  // tile bytes; 128-B rows per key; ...
+    static_assert(HD == 64 || HD == 128, "head widths built on MFMA");
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // K[2] | Vt[2], TB bytes each (16 KiB at HD = 64)
+    char *Ks = smem, *Vs = smem + 2 * TB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     int qblk, bh;
     xcd_remap2(qblk, bh);
     const int q0 = (qblk * 4 + wave) * 32;
     const bool active = q0 < N;
-    const float *Qb = Q + (int64_t)bh * npad * 64;
-    const float *Kb = Kk + (int64_t)bh * npad * 64;
-    const float *Vb = Vt + (int64_t)bh * 64 * npad;
+    const float *Qb = Q + (int64_t)bh * npad * HD;
+    const float *Kb = Kk + (int64_t)bh * npad * HD;
+    const float *Vb = Vt + (int64_t)bh * HD * npad;
 
-    f32x4 qf[2][4];  // [half of d][chunk c]: d = 32*half + 16*h + 4*c + e
+    f32x4 qf[NHF][4];  // [32-wide part of d][chunk c]: d = 32*part + 16*h + 4*c + e
     {
         const int qrow = min(q0 + r, N - 1);
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
+        for (int hf = 0; hf < NHF; ++hf)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) qf[hf][c] = *(const f32x4 *)(Qb + (int64_t)qrow * 64 + 32 * hf + 16 * h + 4 * c);
+            for (int c = 0; c < 4; ++c) qf[hf][c] = *(const f32x4 *)(Qb + (int64_t)qrow * HD + 32 * hf + 16 * h + 4 * c);
     }
-    // staging: 1024 K chunks + 1024 V^T chunks of 16 B per tile, 256 threads -> 4 + 4 each
-    f32x4 rk[4], rv[4];
+    // staging: 16 HD K chunks + 16 HD V^T chunks of 16 B per tile, 256 threads -> HD / 16 each. K: LDS row = RPK * key + part
+    // (a key's HD floats are RPK rows of 128 B); V^T: LDS row = 2 * d + half of the 64-key run
+    f32x4 rk[CPT], rv[CPT];
     auto issue = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int qd = tid + 256 * i, row = qd >> 3, c = qd & 7;  // LDS row (0..127), chunk
-            const int key = min(kt * 64 + (row >> 1), N - 1);
-            rk[i] = *(const f32x4 *)(Kb + (int64_t)key * 64 + (row & 1) * 32 + c * 4);
+        for (int i = 0; i < CPT; ++i) {
+            const int qd = tid + 256 * i, row = qd >> 3, c = qd & 7;  // LDS row, chunk
+            const int key = min(kt * 64 + row / RPK, N - 1);
+            rk[i] = *(const f32x4 *)(Kb + (int64_t)key * HD + (row % RPK) * 32 + c * 4);
             const int d = row >> 1, key0 = kt * 64 + (row & 1) * 32 + c * 4;  // V^T row d, 4 keys
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (key0 < npad) {  // npad % 8 == 0 and key0 % 4 == 0: the 16-B load stays inside the row
@@ -482,16 +504,18 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float *__restri
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < CPT; ++i) {
             const int qd = tid + 256 * i, row = qd >> 3, c = qd & 7;
-            *(f32x4 *)(Ks + buf * 16384 + lds_off(row, c)) = rk[i];
-            *(f32x4 *)(Vs + buf * 16384 + lds_off(row, c)) = rv[i];
+            *(f32x4 *)(Ks + buf * TB + lds_off(row, c)) = rk[i];
+            *(f32x4 *)(Vs + buf * TB + lds_off(row, c)) = rv[i];
         }
     };
 
-    f32x16 O[2];
+    f32x16 O[NDB];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) O[0][e] = O[1][e] = 0.f;
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) O[db][e] = 0.f;
     float m = -INFINITY, l = 0.f;
     const int ntiles = (N + 63) >> 6;
     issue(0);
@@ -501,17 +525,17 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float *__restri
         const int buf = kt & 1;
         if (kt + 1 < ntiles) issue(kt + 1);
         if (active) {
-            const char *Kt = Ks + buf * 16384, *Vtile = Vs + buf * 16384;
+            const char *Kt = Ks + buf * TB, *Vtile = Vs + buf * TB;
             f32x16 S[2];
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) S[sub][e] = 0.f;
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf)
+                for (int hf = 0; hf < NHF; ++hf)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const f32x4 a = *(const f32x4 *)(Kt + lds_off(2 * (sub * 32 + r) + hf, c + 4 * h));
+                        const f32x4 a = *(const f32x4 *)(Kt + lds_off(RPK * (sub * 32 + r) + hf, c + 4 * h));
 #pragma unroll
                         for (int e = 0; e < 4; ++e) S[sub] = mfma32f(a[e], qf[hf][c][e], S[sub]);
                     }
@@ -542,10 +566,9 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float *__restri
             l = fmaf(l, alpha, ps);
             if (WANT_O) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    O[0][e] *= alpha;
-                    O[1][e] *= alpha;
-                }
+                for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) O[db][e] *= alpha;
                 // registers 4g..4g+3 of S[sub] = keys sub*32 + 8g + 4h + (0..3): one 16-B read of V^T
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
@@ -553,7 +576,7 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float *__restri
                     for (int g = 0; g < 4; ++g) {
                         const int chunk = sub * 8 + 2 * g + h;  // 4-key chunk index inside the 64-key row
 #pragma unroll
-                        for (int db = 0; db < 2; ++db) {
+                        for (int db = 0; db < NDB; ++db) {
                             const f32x4 a = *(const f32x4 *)(Vtile + lds_off(2 * (db * 32 + r) + (chunk >> 3), chunk & 7));
 #pragma unroll
                             for (int e = 0; e < 4; ++e) O[db] = mfma32f(a[e], S[sub][4 * g + e], O[db]);
@@ -572,9 +595,9 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float *__restri
         if (WANT_O) {
             const float inv = 1.0f / lt;
             const int b = bh / H, head = bh - b * H;
-            float *dst = ctx + ((int64_t)b * N + qrow) * (H * 64) + head * 64;
+            float *dst = ctx + ((int64_t)b * N + qrow) * (H * HD) + head * HD;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < NDB; ++db)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 o;
@@ -586,24 +609,26 @@ __global__ __launch_bounds__(256) void attn_fwd_f32_kernel(const float *__restri
     }
 }
 
+template <int HD = 64>
 __global__ __launch_bounds__(256) void attn_probs_f32_kernel(const float *__restrict__ Q, const float *__restrict__ Kk,
                                                              const float *__restrict__ lse2, float *__restrict__ attn,
                                                              int N, int npad, float scale2) {
+    constexpr int NHF = HD / 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     int qblk, bh;
     xcd_remap2(qblk, bh);
     const int q0 = (qblk * 4 + wave) * 32;
     if (q0 >= N) return;
-    const float *Qb = Q + (int64_t)bh * npad * 64;
-    const float *Kb = Kk + (int64_t)bh * npad * 64;
-    f32x4 qf[2][4];
+    const float *Qb = Q + (int64_t)bh * npad * HD;
+    const float *Kb = Kk + (int64_t)bh * npad * HD;
+    f32x4 qf[NHF][4];
     {
         const int qrow = min(q0 + r, N - 1);
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
+        for (int hf = 0; hf < NHF; ++hf)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) qf[hf][c] = *(const f32x4 *)(Qb + (int64_t)qrow * 64 + 32 * hf + 16 * h + 4 * c);
+            for (int c = 0; c < 4; ++c) qf[hf][c] = *(const f32x4 *)(Qb + (int64_t)qrow * HD + 32 * hf + 16 * h + 4 * c);
     }
     float lr[16];
 #pragma unroll
@@ -616,10 +641,10 @@ __global__ __launch_bounds__(256) void attn_probs_f32_kernel(const float *__rest
 #pragma unroll
         for (int e = 0; e < 16; ++e) S[e] = 0.f;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf)
+        for (int hf = 0; hf < NHF; ++hf)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x4 kf = *(const f32x4 *)(Kb + (int64_t)key * 64 + 32 * hf + 16 * h + 4 * c);
+                const f32x4 kf = *(const f32x4 *)(Kb + (int64_t)key * HD + 32 * hf + 16 * h + 4 * c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) S = mfma32f(qf[hf][c][e], kf[e], S);  // rows = queries, col (lane) = key
             }
@@ -2044,10 +2069,31 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
                                                                               scale * LOG2E, 0);
         return hipGetLastError();
     }
-    if (head_dim != 64) return hipErrorInvalidValue;
+    if (head_dim != 64 && head_dim != 128) return hipErrorInvalidValue;
     if (!prec)
         return launch_attention_bf16((const bf16 *)q, (const bf16 *)k, (const bf16 *)vt, (bf16 *)ctx, lse2, batch,
-                                     n_tokens, n_pad, heads, scale, s);
+                                     n_tokens, n_pad, heads, scale, s, head_dim);
+    if (prec == 1 && head_dim == 128) {  // 128-wide heads in fp32 precision: the streaming kernel on 128 KiB of dynamic LDS
+        const dim3 g128(((n_tokens + 31) / 32 + 3) / 4, batch * heads), b128(256);
+        constexpr int LDSF = 4 * 128 * 256;
+        static unsigned long long optin[2] = {0, 0};
+        int dev = 0;
+        if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+        const void *kern = ctx ? (const void *)attn_fwd_f32_kernel<true, 128> : (const void *)attn_fwd_f32_kernel<false, 128>;
+        unsigned long long &mask = optin[ctx ? 1 : 0];
+        if (!(mask >> (dev & 63) & 1)) {
+            if (hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSF); e != hipSuccess) return e;
+            mask |= 1ull << (dev & 63);
+        }
+        if (ctx)
+            attn_fwd_f32_kernel<true, 128><<<g128, b128, LDSF, s>>>((const float *)q, (const float *)k, (const float *)vt,
+                                                                    (float *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+        else
+            attn_fwd_f32_kernel<false, 128><<<g128, b128, LDSF, s>>>((const float *)q, (const float *)k, (const float *)vt,
+                                                                     (float *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+        return hipGetLastError();
+    }
+    if (head_dim != 64) return hipErrorInvalidValue;
     const int qtiles = (n_tokens + 31) / 32;
     const dim3 grid((qtiles + 3) / 4, batch * heads), block(256);
     if (prec == 2) {
@@ -2160,12 +2206,13 @@ hipError_t launch_attention(int prec, const void *q, const void *k, const void *
 #undef OCM_X3_ATTN
         return hipGetLastError();
     }
+    constexpr int LDSF64 = 4 * 64 * 256;  // 64 KiB: K[2] | Vt[2]
     if (ctx)
-        attn_fwd_f32_kernel<true><<<grid, block, 0, s>>>((const float *)q, (const float *)k, (const float *)vt,
-                                                         (float *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+        attn_fwd_f32_kernel<true><<<grid, block, LDSF64, s>>>((const float *)q, (const float *)k, (const float *)vt,
+                                                              (float *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
     else
-        attn_fwd_f32_kernel<false><<<grid, block, 0, s>>>((const float *)q, (const float *)k, (const float *)vt,
-                                                          (float *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
+        attn_fwd_f32_kernel<false><<<grid, block, LDSF64, s>>>((const float *)q, (const float *)k, (const float *)vt,
+                                                               (float *)ctx, lse2, n_tokens, n_pad, heads, scale * LOG2E);
     return hipGetLastError();
 }
 
@@ -2183,16 +2230,25 @@ hipError_t launch_attention_probs(int prec, const void *q, const void *k, const 
                                                           scale * LOG2E);
         return hipGetLastError();
     }
+    if (head_dim == 128) {  // 128-wide heads in the fp32 / single-bf16 precisions
+        if (prec)
+            attn_probs_f32_kernel<128><<<grid, block, 0, s>>>((const float *)q, (const float *)k, lse2, attn, n_tokens, n_pad,
+                                                              scale * LOG2E);
+        else
+            attn_probs_kernel<128><<<grid, block, 0, s>>>((const bf16 *)q, (const bf16 *)k, lse2, attn, n_tokens, n_pad,
+                                                          scale * LOG2E);
+        return hipGetLastError();
+    }
     if (head_dim != 64) return hipErrorInvalidValue;
     if (prec == 2)
         attn_probs_x3_kernel<64><<<gridz, block, 0, s>>>((const char *)q, (const char *)k, lse2, attn, n_tokens, n_pad,
                                                      scale * LOG2E);
     else if (prec)
-        attn_probs_f32_kernel<<<grid, block, 0, s>>>((const float *)q, (const float *)k, lse2, attn, n_tokens, n_pad,
-                                                     scale * LOG2E);
+        attn_probs_f32_kernel<64><<<grid, block, 0, s>>>((const float *)q, (const float *)k, lse2, attn, n_tokens, n_pad,
+                                                         scale * LOG2E);
     else
-        attn_probs_kernel<<<grid, block, 0, s>>>((const bf16 *)q, (const bf16 *)k, lse2, attn, n_tokens, n_pad,
-                                                 scale * LOG2E);
+        attn_probs_kernel<64><<<grid, block, 0, s>>>((const bf16 *)q, (const bf16 *)k, lse2, attn, n_tokens, n_pad,
+                                                     scale * LOG2E);
     return hipGetLastError();
 }
 
@@ -2296,9 +2352,16 @@ hipError_t launch_attention_rows(int prec, const void *q, const void *k, const i
     if (n_rows <= 0) return hipSuccess;
     const dim3 grid(n_rows, batch * heads), block(64);
     const size_t lds = (size_t)n_tokens * sizeof(float);
-    if (head_dim == 128 && prec == 2) {
-        attn_rows_kernel<sp32, 128><<<grid, block, lds, s>>>((const sp32 *)q, (const sp32 *)k, query_rows, n_rows, rows,
-                                                             n_tokens, n_pad, scale * LOG2E);
+    if (head_dim == 128) {
+        if (prec == 2)
+            attn_rows_kernel<sp32, 128><<<grid, block, lds, s>>>((const sp32 *)q, (const sp32 *)k, query_rows, n_rows, rows,
+                                                                 n_tokens, n_pad, scale * LOG2E);
+        else if (prec)
+            attn_rows_kernel<float, 128><<<grid, block, lds, s>>>((const float *)q, (const float *)k, query_rows, n_rows, rows,
+                                                                  n_tokens, n_pad, scale * LOG2E);
+        else
+            attn_rows_kernel<bf16, 128><<<grid, block, lds, s>>>((const bf16 *)q, (const bf16 *)k, query_rows, n_rows, rows,
+                                                                 n_tokens, n_pad, scale * LOG2E);
         return hipGetLastError();
     }
     if (head_dim != 64) return hipErrorInvalidValue;

@@ -129,9 +129,9 @@ class Attention(nn.Module):
         if Cd % H or (Cd // H) % 8:
             raise ValueError(f"dim {Cd} / num_heads {H}: the HIP kernels need a head width that is a multiple of 8")
         hd = Cd // H
-        # 64-wide heads, and 128-wide ones in split-bf16 precision (model.py:93-103), run the MFMA attention kernels; any other
-        # width (the reference accepts every dim / num_heads, :66-90) the generic fp32 kernel on the fp32 qkv tensor
-        mfma = hd == 64 or (hd == 128 and pc == _lib.OCM_PREC_BF16X3)
+        # 64- and 128-wide heads (model.py:93-103) run the MFMA attention kernels in every precision; any other width (the
+        # reference accepts every dim / num_heads, :66-90) the generic fp32 kernel on the fp32 qkv tensor
+        mfma = hd in (64, 128)
         x32 = _f32c(x).reshape(B * N, Cd)
         dev, npad, adt = x32.device, lib.ocm_n_pad_prec(pc, N), _ACT_DTYPE[pc]
         with torch.cuda.device(dev):
