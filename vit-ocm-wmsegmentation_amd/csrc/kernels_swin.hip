@@ -440,11 +440,16 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
     }
     const bool masked = g.shift > 0 && (wy == g.H / ws - 1 || wx == g.nWx - 1);  // wave-uniform
     if (masked) Rg[lane] = (unsigned char)(lane < A ? win_region(g, ws, wy, wx, lane) : 0);
+    const int pr = pi_row(r);
+    const float *bp = bias_perm + (size_t)head * 2 * 64 * 32 + lane * 4;
+    f32x4 bvq[2][8];  // the relative-position bias of both query tiles, requested with the K / V / Q burst
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) bvq[qt][c8] = *(const f32x4 *)(bp + qt * 64 * 32 + c8 * 256);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 
-    const int pr = pi_row(r);
-    const float *bp = bias_perm + (size_t)head * 2 * 64 * 32 + lane * 4;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         if (qt * 32 >= A) break;
@@ -460,14 +465,13 @@ __global__ __launch_bounds__(256) void swin_wattn_kernel(const bf16 *__restrict_
                 S[sub] = mfma32(a, qf[qt][s], S[sub]);
             }
         }
-        const float *bq = bp + qt * 64 * 32;
         float mx = -INFINITY;
         const int myreg = masked ? Rg[min(qi, A - 1)] : 0;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
-                const f32x4 bv = *(const f32x4 *)(bq + (sub * 4 + e4) * 256);
+                const f32x4 bv = bvq[qt][sub * 4 + e4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = fmaf(S[sub][e4 * 4 + e], scale2, bv[e]);
@@ -600,11 +604,18 @@ __global__ __launch_bounds__(WATTN_X3_WAVES * 64) void swin_wattn_x3_kernel(cons
     }
     const bool masked = g.shift > 0 && (wy == g.H / ws - 1 || wx == g.nWx - 1);  // wave-uniform
     if (masked) Rg[lane] = (unsigned char)(lane < A ? win_region(g, ws, wy, wx, lane) : 0);
+    const int pr = pi_row(r);
+    const float *bp = bias_perm + (size_t)head * 2 * 64 * 32 + lane * 4;
+    // the relative-position bias of both query tiles, requested with the K / V / Q burst (one L2 round trip per tile was exposed
+    // between the score MFMAs and the softmax before)
+    f32x4 bvq[2][8];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) bvq[qt][c8] = *(const f32x4 *)(bp + qt * 64 * 32 + c8 * 256);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 
-    const int pr = pi_row(r);
-    const float *bp = bias_perm + (size_t)head * 2 * 64 * 32 + lane * 4;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         if (qt * 32 >= A) break;
@@ -621,14 +632,13 @@ __global__ __launch_bounds__(WATTN_X3_WAVES * 64) void swin_wattn_x3_kernel(cons
                 S[sub] = mfma32x3(kh, kl, qh[qt][s], ql[qt][s], S[sub]);
             }
         }
-        const float *bq = bp + qt * 64 * 32;
         float mx = -INFINITY;
         const int myreg = masked ? Rg[min(qi, A - 1)] : 0;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
-                const f32x4 bv = *(const f32x4 *)(bq + (sub * 4 + e4) * 256);
+                const f32x4 bv = bvq[qt][sub * 4 + e4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = fmaf(S[sub][e4 * 4 + e], scale2, bv[e]);
