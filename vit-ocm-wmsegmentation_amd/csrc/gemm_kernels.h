@@ -257,6 +257,19 @@ struct EpiResidStats {
         constexpr int BM = Cfg::BM, BN = Cfg::BN, NT = Cfg::NT, NV = BN / 64, RPP = NT / 8;
         static_assert(BN % 64 == 0 && NT % 64 == 0, "eight lanes x eight columns per chunk");
         const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+        // the residual rows of ALL passes are requested before the first pass stores anything: x is updated in place (resid
+        // aliases x), so hipcc keeps a later pass's loads behind an earlier pass's stores — one more exposed L2 round trip per pass
+        constexpr int NPASS = (BM + RPP - 1) / RPP, NPRE = NPASS <= 2 ? NPASS : 1;
+        f32x4 pre[NPRE][NV][2];
+#pragma unroll
+        for (int ps = 0; ps < NPRE; ++ps) {
+            const int64_t mo = (int64_t)min(m0 + ps * RPP + grp, M - 1) * N;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                pre[ps][i][0] = *(const f32x4 *)(resid + mo + n0 + sub * 8 + i * 64);
+                pre[ps][i][1] = *(const f32x4 *)(resid + mo + n0 + sub * 8 + i * 64 + 4);
+            }
+        }
 #pragma unroll 2
         for (int r0 = 0; r0 < BM; r0 += RPP) {
             const int row = r0 + grp, m = m0 + row;
@@ -265,8 +278,13 @@ struct EpiResidStats {
             f32x4 v[NV][2];
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                v[i][0] = *(const f32x4 *)(resid + mo + n0 + sub * 8 + i * 64);
-                v[i][1] = *(const f32x4 *)(resid + mo + n0 + sub * 8 + i * 64 + 4);
+                if (NPRE == NPASS) {
+                    v[i][0] = pre[NPASS == 2 && r0 ? 1 : 0][i][0];
+                    v[i][1] = pre[NPASS == 2 && r0 ? 1 : 0][i][1];
+                } else {
+                    v[i][0] = *(const f32x4 *)(resid + mo + n0 + sub * 8 + i * 64);
+                    v[i][1] = *(const f32x4 *)(resid + mo + n0 + sub * 8 + i * 64 + 4);
+                }
             }
             float sh = 0.f;
             if (shift) {  // the eight lanes of the row add the previous site's slots (fixed tree: the same bits in every tile)
